@@ -1,0 +1,157 @@
+"""CPU tier: the HIP kernel sources compiled for the host (tests/emu) + the planner, checked against the
+oracle on seeded inputs.  Validates index math, LDS layouts, barrier placement, twiddle tables and
+routing without a GPU; the -m gpu tests repeat the same comparisons on the real kernels."""
+import numpy as np
+import pytest
+
+import emu_harness as emu
+from mi355fft import _abi
+
+TOL = 1e-5  # north_star: 1e-5 relative (norm-relative)
+
+
+def check(got, want, what, tol=TOL):
+    from oracle import oracle as orc
+    l2, mx = orc.rel_l2(got, want), orc.rel_max(got, want)
+    assert l2 <= tol and mx <= tol, f"{what}: rel_l2={l2:.3e} rel_max={mx:.3e}"
+
+
+def test_registry_matches_device_constants():
+    import ctypes
+    msg = ctypes.create_string_buffer(256)
+    assert emu.lib().emu_check_registry(msg, 256) == 0, msg.value
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("direction", ["forward", "inverse"])
+def test_c2c_row_lines(oracle, n, direction):
+    batch = 5 if n <= 1024 else 3          # not a multiple of the tile: exercises the masked tail lines
+    x = oracle.random_complex_batch(n, batch, 0xA000 + n).reshape(-1)
+    norm = "unitary" if direction == "forward" else "backward"
+    desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+    got, route, launches = emu.run_plan(desc, x, x.size)
+    assert route.startswith("lines[") and launches == 1
+    check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"c2c N={n} {direction}")
+
+
+def test_c2c_in_place(oracle):
+    x = oracle.random_complex_batch(256, 3, 7).reshape(-1)
+    desc = _abi.make_desc("c2c", [256], 3, "forward", "none", in_place=True)
+    got, _, _ = emu.run_plan(desc, x, x.size)
+    check(got, oracle.c2c_ref_batch(x, [256], 3, "forward"), "in-place")
+
+
+@pytest.mark.parametrize("lg,direction", [(13, "forward"), (13, "inverse"), (14, "forward"), (15, "inverse"), (16, "forward"), (17, "forward")])
+def test_c2c_two_pass(oracle, lg, direction):
+    n, batch = 1 << lg, 3
+    x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
+    desc = _abi.make_desc("c2c", [n], batch, direction, "backward")
+    got, route, launches = emu.run_plan(desc, x, x.size, chunk_bytes=2 * n * 8)   # 2 transforms per chunk -> 2 chunks
+    assert route.startswith("two-pass[") and launches == 4
+    check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"two-pass 2^{lg} {direction}")
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 24, 96, 105, 210, 1001, 8 * 13 * 11])
+def test_c2c_generic_mixed_radix(oracle, n):
+    batch = 2
+    x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc = _abi.make_desc("c2c", [n], batch, direction, "none")
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert route.startswith("stages[")
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"generic N={n} {direction}", 2e-6 if n < 1000 else 1e-5)
+
+
+def test_c2c_generic_route_matches_lines_route(oracle):
+    x = oracle.random_complex_batch(1024, 2, 3).reshape(-1)
+    desc = _abi.make_desc("c2c", [1024], 2, "forward", "none")
+    a, _, _ = emu.run_plan(desc, x, x.size)
+    b, route, _ = emu.run_plan(desc, x, x.size, force_generic=True)
+    assert route.startswith("stages[")
+    check(a, b, "routes agree", 2e-6)
+
+
+@pytest.mark.parametrize("shape", [[8, 4], [16, 16], [4, 8, 2], [12, 5], [64, 3, 2]])
+def test_c2c_nd(oracle, shape):
+    n, batch = int(np.prod(shape)), 2
+    x = oracle.random_complex_batch(n, batch, 0xD000 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc = _abi.make_desc("c2c", shape, batch, direction, "unitary")
+        got, _, _ = emu.run_plan(desc, x, x.size)
+        check(got, oracle.c2c_ref_batch(x, shape, batch, direction, "unitary"), f"nd {shape} {direction}")
+
+
+def test_unsupported_prime_is_a_clean_error():
+    desc = _abi.make_desc("c2c", [17], 1, "forward", "none")
+    with pytest.raises(emu.EmuError) as e:
+        emu.run_plan(desc, np.zeros(34, np.float32), 34)
+    assert e.value.code == _abi.ERR_UNSUPPORTED and "Bluestein" in str(e.value)
+
+
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 16384, 6, 10, 12, 30, 9, 15, 21])
+def test_r2c_and_c2r(oracle, n):
+    batch = 3
+    x = oracle.random_real_batch(n, batch, 0xE000 + n).reshape(-1)
+    p = n // 2 + 1
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    desc = _abi.make_desc("r2c", [n], batch, "forward", "none")
+    got, route, _ = emu.run_plan(desc, x, 2 * p * batch)
+    check(got, want, f"r2c N={n} ({route})", 1e-5)
+    # c2r of the oracle's packed spectrum, backward-normalised, returns the signal
+    desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward")
+    back, route, _ = emu.run_plan(desc, want, n * batch)
+    want_back = np.concatenate([oracle.c2r_ref_from_packed(want[2 * b * p:2 * (b + 1) * p], n, "backward") for b in range(batch)])
+    check(back, want_back, f"c2r N={n} ({route})", 1e-5)
+    check(back, x, f"c2r(r2c) round trip N={n}", 1e-5)
+
+
+def test_c2r_ignores_imag_of_self_conjugate_bins(oracle):
+    n = 64
+    x = oracle.random_real(n, 5)
+    spec = oracle.r2c_ref_packed(x, n, "none").copy()
+    spec[1] = 3.25        # imag of bin 0
+    spec[2 * (n // 2) + 1] = -7.5  # imag of bin N/2
+    desc = _abi.make_desc("c2r", [n], 1, "inverse", "backward")
+    got, _, _ = emu.run_plan(desc, spec, n)
+    check(got, oracle.c2r_ref_from_packed(spec, n, "backward"), "self-conjugate bins")
+    check(got, x, "self-conjugate bins vs signal")
+
+
+def test_r2c_rejects_inverse_and_c2r_rejects_forward():
+    for typ, direction, frag in (("r2c", "inverse", "forward"), ("c2r", "forward", "inverse")):
+        desc = _abi.make_desc(typ, [16], 1, direction, "none")
+        with pytest.raises(emu.EmuError) as e:
+            emu.run_plan(desc, np.zeros(64, np.float32), 64)
+        assert e.value.code == _abi.ERR_INVALID and frag in str(e.value)
+
+
+def test_r2c_2d(oracle):
+    shape, batch = [16, 4], 2
+    n = 64
+    x = oracle.random_real_batch(n, batch, 11).reshape(-1)
+    p = shape[0] // 2 + 1
+    want = []
+    for b in range(batch):
+        cplx = np.zeros(2 * n, np.float32)
+        cplx[0::2] = x[b * n:(b + 1) * n]
+        full = oracle.fftnd_ref(cplx, shape, "forward", "none").reshape(shape[1], shape[0], 2)
+        want.append(full[:, :p, :].reshape(-1))
+    want = np.concatenate(want)
+    desc = _abi.make_desc("r2c", shape, batch, "forward", "none")
+    got, _, _ = emu.run_plan(desc, x, want.size)
+    check(got, want, "r2c 2-D")
+    desc = _abi.make_desc("c2r", shape, batch, "inverse", "backward")
+    back, _, _ = emu.run_plan(desc, want, n * batch)
+    check(back, x, "c2r 2-D round trip")
+
+
+def test_support_kernels_match_oracle_prng(oracle):
+    import ctypes
+    rows, row_floats = 3, 2 * 50
+    out = np.zeros(rows * row_floats, np.float32)
+    emu.lib().emu_fill_random(out.ctypes.data, row_floats, rows, 0x5EED0002, 7)
+    want = oracle.random_complex_batch(50, rows, 0x5EED0002, b0=7).reshape(-1)
+    assert np.array_equal(out, want)
+    s = ctypes.c_double()
+    emu.lib().emu_diff_sumsq(out.ctypes.data, None, 0.0, out.size, ctypes.byref(s))
+    assert abs(s.value - float(np.sum(out.astype(np.float64) ** 2))) < 1e-9

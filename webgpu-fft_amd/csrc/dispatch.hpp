@@ -1,0 +1,145 @@
+// dispatch.hpp — turns one planned Step (plan.hpp) with resolved pointers into a kernel launch.
+//
+// Shared by the product launcher (api.hip: HipLauncher enqueues on the device stream or a capturing
+// stream — the "hipGraph stage executor" that replaces the per-stage beginComputePass/dispatchWorkgroups
+// loop of src/plan.js:1233-1273) and by the host emulation in tests/emu (EmuLauncher).
+//
+// A Launcher provides:
+//   template <class... P, class... A> void launch(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args);
+//   void copy(void* dst, const void* src, size_t bytes);
+#pragma once
+#include "kern_generic.hpp"
+#include "kern_lines.hpp"
+#include "plan.hpp"
+
+namespace mi355 {
+
+// line-kernel families: one translation unit each so the device code builds in parallel
+enum : int { FAM_ROW_SMALL = 0, FAM_ROW_1K = 1, FAM_ROW_BIG = 2, FAM_PASS_A = 3, FAM_PASS_B = 4, FAM_COUNT = 5 };
+constexpr int row_family(int N) { return N <= 256 ? FAM_ROW_SMALL : (N <= 1024 ? FAM_ROW_1K : FAM_ROW_BIG); }
+
+template <int FAMILY, class L>
+bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
+  int cur = 0;
+#define MI_LINE_CASE(FAM, N, R0, R1, R2, T, IC, OC, SI, SO, TW)                          \
+  if (id == cur) {                                                                       \
+    if constexpr ((FAM) == FAMILY) {                                                     \
+      using C = LineCfg<N, R0, R1, R2, T, IC, OC, SI, SO, TW>;                           \
+      l.launch(fft_lines_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+      return true;                                                                       \
+    } else return false;                                                                 \
+  }                                                                                      \
+  ++cur;
+#define LINE_ROW(N, R0, R1, R2, T)                                          \
+  MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, false, false, 0) \
+  MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, true, true, 0)
+#define LINE_PASS_A(N, R0, R1, R2, T)                               \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 1) \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 1)
+#define LINE_PASS_B(N, R0, R1, R2, T)                                \
+  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, false, 0) \
+  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, true, 0)
+#include "line_kernels.def"
+#undef LINE_ROW
+#undef LINE_PASS_A
+#undef LINE_PASS_B
+#undef MI_LINE_CASE
+  (void)cur; (void)a; (void)grid; (void)l;
+  return false;
+}
+
+inline int family_of_line_kernel(const LineKernelMeta& m) {
+  if (m.in_col && m.out_col) return FAM_PASS_A;
+  if (!m.in_col && m.out_col) return FAM_PASS_B;
+  return row_family(m.N);
+}
+
+template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
+  switch (radix) {
+#define MI_STAGE_CASE(R) case R: l.launch(stockham_stage_kernel<R>, grid, 256u, 0u, a); return true;
+    MI_STAGE_CASE(2) MI_STAGE_CASE(3) MI_STAGE_CASE(4) MI_STAGE_CASE(5) MI_STAGE_CASE(7) MI_STAGE_CASE(8)
+    MI_STAGE_CASE(11) MI_STAGE_CASE(13) MI_STAGE_CASE(16) MI_STAGE_CASE(32)
+#undef MI_STAGE_CASE
+  }
+  return false;
+}
+
+// LinesFn: bool(int family, int id, const LineArgs&, unsigned grid) — supplied by the caller because the
+// per-family instantiations live in different translation units in the product build.
+template <class L, class LinesFn>
+bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) {
+  switch (s.kind) {
+    case ST_LINES: {
+      LineArgs a{};
+      a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2]; a.tw_lo = (const cf*)ptr[3]; a.tw_hi = (const cf*)ptr[4];
+      a.num_tiles = s.i[0]; a.num_lines = s.i[1];
+      a.in_S = s.i[2]; a.in_outer_stride = s.i[3]; a.out_S = s.i[4]; a.out_outer_stride = s.i[5];
+      a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7];
+      a.scale = s.f[0];
+      const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
+      return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);
+    }
+    case ST_STAGE: {
+      StageArgs a{};
+      a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
+      a.total = s.i[0]; a.N = s.i[1]; a.S = s.i[2]; a.Nsp = s.i[3]; a.swap_in = (int)s.i[4]; a.swap_out = (int)s.i[5];
+      a.scale = s.f[0];
+      return launch_stage(s.variant, a, s.grid, l);
+    }
+    case ST_R2C_POST: {
+      R2cPostArgs a{};
+      a.z = (const cf*)ptr[0]; a.x = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
+      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2]; a.scale = s.f[0];
+      l.launch(r2c_post_kernel, s.grid, 256u, 0u, a);
+      return true;
+    }
+    case ST_C2R_PRE: {
+      C2rPreArgs a{};
+      a.x = (const cf*)ptr[0]; a.z = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
+      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2];
+      l.launch(c2r_pre_kernel, s.grid, 256u, 0u, a);
+      return true;
+    }
+    case ST_REAL_TO_COMPLEX:
+      l.launch(real_to_complex_kernel, s.grid, 256u, 0u, (const float*)ptr[0], (cf*)ptr[1], (long long)s.i[0]);
+      return true;
+    case ST_COMPLEX_TO_REAL:
+      l.launch(complex_to_real_kernel, s.grid, 256u, 0u, (const cf*)ptr[0], (float*)ptr[1], (long long)s.i[0], s.f[0]);
+      return true;
+    case ST_PACK_HALF:
+      l.launch(pack_half_kernel, s.grid, 256u, 0u, (const cf*)ptr[0], (cf*)ptr[1], (long long)s.i[0], (long long)s.i[1], (long long)s.i[2],
+               (long long)s.i[3], s.f[0]);
+      return true;
+    case ST_UNPACK_HERM:
+      l.launch(unpack_hermitian_kernel, s.grid, 256u, 0u, (const cf*)ptr[0], (cf*)ptr[1], (long long)s.i[0], (long long)s.i[1],
+               (long long)s.i[2], (long long)s.i[3]);
+      return true;
+    case ST_POINTWISE:
+      l.launch(pointwise_mul_kernel, s.grid, 256u, 0u, (const cf*)ptr[0], (cf*)ptr[1], (const cf*)ptr[2], (long long)s.i[0], (long long)s.i[1],
+               (int)s.i[2], s.f[0]);
+      return true;
+    case ST_GATHER:
+    case ST_SCATTER: {
+      StridedArgs a{};
+      a.src = (const cf*)ptr[0]; a.dst = (cf*)ptr[1];
+      a.total = s.i[0]; a.per = s.i[1]; a.rank = (int)s.i[2];
+      a.phys_offset = s.i[3]; a.phys_batch_stride = s.i[4]; a.dense_offset = s.i[5]; a.dense_batch_stride = s.i[6];
+      for (int d = 0; d < 8; ++d) { a.shape[d] = s.shape[d] ? s.shape[d] : 1; a.phys_stride[d] = s.sa[d]; a.dense_stride[d] = s.sb[d]; }
+      if (s.kind == ST_GATHER) l.launch(strided_copy_kernel<true>, s.grid, 256u, 0u, a);
+      else l.launch(strided_copy_kernel<false>, s.grid, 256u, 0u, a);
+      return true;
+    }
+    case ST_ZERO:
+      l.launch(zero_kernel, s.grid, 256u, 0u, (float*)ptr[0], (long long)s.i[0]);
+      return true;
+    case ST_SCALE:
+      l.launch(scale_kernel, s.grid, 256u, 0u, (float*)ptr[0], (long long)s.i[0], s.f[0]);
+      return true;
+    case ST_COPY:
+      if (ptr[0] != ptr[1]) l.copy(ptr[1], ptr[0], (size_t)s.i[0]);
+      return true;
+  }
+  return false;
+}
+
+}  // namespace mi355

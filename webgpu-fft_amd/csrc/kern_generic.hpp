@@ -1,0 +1,239 @@
+// kern_generic.hpp — the route for everything the LDS line kernels do not cover (mixed radix 3/5/7/11/13,
+// lines longer than the two-pass limit) plus the memory-bound glue kernels of the r2c / c2r / fftconv
+// plans and the test/bench support kernels.
+//
+// Reference counterparts (paths into the reference repo):
+//   stockham_stage_kernel   src/kernels/stockham_stage.js:17-106 — one Stockham stage, global -> global;
+//                           one lane per BUTTERFLY (R loads, R stores) instead of one per output element
+//                           (R loads, 1 store), roots from an f64-built table instead of in-shader cis().
+//   scale_kernel            src/kernels/scale.js:3-30
+//   r2c_post_kernel         src/kernels/real_complex.js:73-114 (pack) — here the half-length trick:
+//                           X[k] from Z = FFT_{N/2}(x[2n] + i x[2n+1]), not a full-length complex FFT
+//   c2r_pre_kernel          src/kernels/real_complex.js:116-201 (Hermitian unpack, self-conjugate bins'
+//                           imaginary parts ignored) folded into the half-length pre-processing
+//   real_to_complex / complex_to_real for odd N: src/kernels/real_complex.js:1-43
+//   pointwise_mul_kernel    src/kernels/fft_conv.js:3-66
+//   gather/scatter_strided  src/kernels/strided_complex.js:22-106
+//   fill_random / sumsq     test + bench support: device twin of oracle.c's PRNG, f64 reductions
+#pragma once
+#include "platform.hpp"
+#include "radix.hpp"
+
+namespace mi355 {
+
+// Lines of an N-D array, axis `a` of length N with element stride S = prod(shape[:a]):
+//   line id L in [0, S*outer) -> inner = L % S, o = L / S; element p at o*S*N + inner + p*S.
+struct StageArgs {
+  const cf* in;
+  cf* out;
+  const cf* tw;        // this stage's table [R][Ns_prev]
+  long long total;     // butterflies = lines * N / R
+  long long N;         // line length
+  long long S;         // element stride of the axis
+  long long Nsp;       // Ns_prev (product of radices already applied)
+  float scale;         // fused into the last stage
+  int swap_in, swap_out;
+};
+
+template <int R>
+__global__ void __launch_bounds__(256) stockham_stage_kernel(const StageArgs a) {
+  const long long nb = a.N / R;  // butterflies per line
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
+    // consecutive threads walk the contiguous direction: inner index fastest when S > 1
+    long long inner, j, o;
+    if (a.S == 1) { o = g / nb; j = g - o * nb; inner = 0; }
+    else { inner = g % a.S; const long long r = g / a.S; j = r % nb; o = r / nb; }
+    const long long base = o * a.S * a.N + inner;
+    const long long k = j % a.Nsp;
+    cf w[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      cf x = a.in[base + (j + q * nb) * a.S];
+      if (a.swap_in) x = x.yx;
+      if (q > 0 && a.Nsp > 1) x = cmul(x, a.tw[q * a.Nsp + k]);
+      w[q] = x;
+    }
+    fft_radix<R>(w);
+    const long long ob = (j / a.Nsp) * (a.Nsp * R) + k;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      cf y = w[q] * a.scale;
+      if (a.swap_out) y = y.yx;
+      a.out[base + (ob + q * a.Nsp) * a.S] = y;
+    }
+  }
+}
+
+// data[i] *= s  (float granularity so the same kernel serves real and complex buffers)
+__global__ void __launch_bounds__(256) scale_kernel(float* data, long long count, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    data[i] *= s;
+}
+
+// r2c, even N, H = N/2.  Z[b][k] (k < H) = FFT_H of z[n] = x[2n] + i x[2n+1]; writes the packed spectrum
+// X[b][k], k = 0..H (H+1 bins per line, reference packing docs/API.md "R2C/C2R packing"):
+//   X[k] = (Z[k] + conj(Z[H-k]))/2 - (i/2) e^{-2 pi i k/N} (Z[k] - conj(Z[H-k])),  Z[H] := Z[0]
+// tw[k] = e^{-2 pi i k/N}, k <= H/2 suffices but the table holds k < H+1.
+struct R2cPostArgs {
+  const cf* z; cf* x; const cf* tw;
+  long long H, batch;
+  long long x_line_stride;  // elements between packed lines (H+1 when dense)
+  float scale;
+};
+__global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
+  const long long per = a.H + 1;
+  const long long total = a.batch * per;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / per, k = g - b * per;
+    const cf* z = a.z + b * a.H;
+    const cf zk = z[k == a.H ? 0 : k];
+    const cf zm = z[k == 0 || k == a.H ? 0 : a.H - k];
+    const cf zmc = {zm.x, -zm.y};
+    const cf e = (zk + zmc) * 0.5f;       // spectrum of the even samples
+    const cf d = (zk - zmc) * 0.5f;       // i * spectrum of the odd samples
+    const cf od = mul_neg_i(d);           // spectrum of the odd samples
+    const cf r = e + cmul(a.tw[k], od);
+    a.x[b * a.x_line_stride + k] = r * a.scale;
+  }
+}
+
+// c2r, even N, H = N/2.  Builds Z[b][k], k < H, such that IFFT_H(Z)[n] = x[2n] + i x[2n+1] (unnormalised
+// by the full-length convention: the 1/2 of the split is absorbed):
+//   E[k] = (X[k] + conj(X[H-k])),  O[k] = (X[k] - conj(X[H-k])) e^{+2 pi i k/N},  Z[k] = E[k] + i O[k]
+// The imaginary parts of X[0] and X[H] are ignored (Hermitian unpack: real_complex.js:147-155,194-197).
+struct C2rPreArgs {
+  const cf* x; cf* z; const cf* tw;   // tw[k] = e^{-2 pi i k/N}
+  long long H, batch;
+  long long x_line_stride;
+};
+__global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
+  const long long total = a.batch * a.H;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / a.H, k = g - b * a.H;
+    const cf* x = a.x + b * a.x_line_stride;
+    cf xk = x[k];
+    cf xm = x[a.H - k];
+    if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }
+    const cf xmc = {xm.x, -xm.y};
+    const cf e = xk + xmc;
+    const cf o = cmul_conj(xk - xmc, a.tw[k]);   // * e^{+2 pi i k/N}
+    a.z[g] = e + mul_pos_i(o);
+  }
+}
+
+// odd-N real paths: expand real -> complex (imag 0) and take the real part
+__global__ void __launch_bounds__(256) real_to_complex_kernel(const float* x, cf* z, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+    cf v = {x[i], 0.0f};
+    z[i] = v;
+  }
+}
+__global__ void __launch_bounds__(256) complex_to_real_kernel(const cf* z, float* x, long long count, float s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    x[i] = z[i].x * s;
+}
+// full complex line (N) -> first N/2+1 bins, and the Hermitian expansion back (odd N route)
+__global__ void __launch_bounds__(256) pack_half_kernel(const cf* full, cf* packed, long long N, long long P, long long batch, long long packed_stride, float s) {
+  const long long total = batch * P;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / P, k = g - b * P;
+    packed[b * packed_stride + k] = full[b * N + k] * s;
+  }
+}
+__global__ void __launch_bounds__(256) unpack_hermitian_kernel(const cf* packed, cf* full, long long N, long long P, long long batch, long long packed_stride) {
+  const long long total = batch * N;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / N, k = g - b * N;
+    cf v;
+    if (k < P) { v = packed[b * packed_stride + k]; if (k == 0 || 2 * k == N) v.y = 0.0f; }
+    else { const cf m = packed[b * packed_stride + (N - k)]; v.x = m.x; v.y = -m.y; }
+    full[g] = v;
+  }
+}
+
+// data[b][i] *= (conj?) kern[i]   — frequency-domain product of fftconv (fft_conv.js:3-31)
+__global__ void __launch_bounds__(256) pointwise_mul_kernel(const cf* data, cf* out, const cf* kern, long long L, long long total, int conj_kernel, float s) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const cf k = kern[g % L];
+    const cf d = data[g];
+    out[g] = (conj_kernel ? cmul_conj(d, k) : cmul(d, k)) * s;
+  }
+}
+
+// Strided physical <-> dense logical, rank <= 8 (strided_complex.js:22-106).  Logical index is axis-0
+// fastest within a batch entry; physical element = offset + b*batch_stride + sum coord_d*stride_d.
+// `sub` selects a window of the dense side: dense coords = coord + sub_offset inside dense_shape
+// (embedding a small kernel / input into a zero-padded FFT domain, or cropping a result).
+struct StridedArgs {
+  const cf* src; cf* dst;
+  long long total;                 // batch * prod(shape)
+  long long per;                   // prod(shape)  (shape = extent of the moved region)
+  int rank;
+  long long shape[8];
+  long long phys_stride[8];
+  long long phys_offset, phys_batch_stride;
+  long long dense_stride[8];       // strides of the dense side's full domain
+  long long dense_offset, dense_batch_stride;
+};
+template <bool GATHER>
+__global__ void __launch_bounds__(256) strided_copy_kernel(const StridedArgs a) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
+    const long long b = g / a.per;
+    long long rem = g - b * a.per;
+    long long p = a.phys_offset + b * a.phys_batch_stride;
+    long long d = a.dense_offset + b * a.dense_batch_stride;
+    for (int i = 0; i < a.rank; ++i) {
+      const long long c = rem % a.shape[i];
+      rem /= a.shape[i];
+      p += c * a.phys_stride[i];
+      d += c * a.dense_stride[i];
+    }
+    if constexpr (GATHER) a.dst[d] = a.src[p]; else a.dst[p] = a.src[d];
+  }
+}
+
+__global__ void __launch_bounds__(256) zero_kernel(float* data, long long count) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) data[i] = 0.0f;
+}
+
+// ---- test / bench support ---------------------------------------------------------------------------
+MI_DEV unsigned mulberry32_at(unsigned seed, unsigned long long n) {
+  unsigned t = seed + (unsigned)((n + 1ull) * 0x6D2B79F5ull);
+  t = (t ^ (t >> 15)) * (t | 1u);
+  t ^= t + (t ^ (t >> 7)) * (t | 61u);
+  return t ^ (t >> 14);
+}
+MI_DEV unsigned stream_seed(unsigned seed0, unsigned long long b) {
+  unsigned h = seed0 + (unsigned)((b + 1ull) * 0x9E3779B9ull);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__global__ void __launch_bounds__(256) fill_random_kernel(float* out, unsigned long long row_floats, unsigned long long rows, unsigned seed0,
+                                                         unsigned long long first_transform) {
+  const unsigned long long total = row_floats * rows;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long r = g / row_floats, i = g - r * row_floats;
+    const unsigned u = mulberry32_at(stream_seed(seed0, first_transform + r), i);
+    const double x = (double)u / 4294967296.0;
+    out[g] = (float)((x * 2.0 - 1.0) * 0.5);
+  }
+}
+
+// partial[block] = sum over the block's grid-stride slice of (a[i] - alpha*b[i])^2 in f64 (b may be null)
+__global__ void __launch_bounds__(256) diff_sumsq_kernel(const float* a, const float* b, double alpha, unsigned long long count, double* partial) {
+  double acc = 0.0;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (unsigned long long)gridDim.x * blockDim.x) {
+    const double d = (double)a[g] - (b ? alpha * (double)b[g] : 0.0);
+    acc += d * d;
+  }
+  MI_SMEM_DECL_STATIC(double, red, 256);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+}  // namespace mi355

@@ -1,0 +1,238 @@
+// kern_lines.hpp — LDS-resident Stockham line FFTs for gfx950: the hot kernels.
+//
+// Replaces, for power-of-two line lengths N <= 4096:
+//   * the per-stage dispatch loop of FftPlan.exec (src/plan.js:1233-1273): S full HBM round trips, one
+//     compute pass per radix stage, become ONE kernel that reads each point once and writes it once;
+//   * generateStockhamRadixStageWGSL (src/kernels/stockham_stage.js:76-103): same autosort index math
+//       in[j + q*N/R]  ->  out[(j / Ns)*Ns*R + (j % Ns) + q*Ns],  twiddle e^{-2 pi i q (j % Ns)/(Ns*R)}
+//     but with the R inputs of a butterfly held by one lane, roots from f64-built tables staged in LDS
+//     (the reference calls cos/sin per thread per stage in f32 and chains w *= w1: ~1e-4 accuracy);
+//   * generateSubgroupPow2FftWGSL (src/kernels/subgroup_pow2_fft.js:8-133): no bit-reverse pass exists
+//     here at all — Stockham stages leave natural order;
+//   * generateTransposeComplex2DWGSL (src/kernels/transpose.js:1-51) and the per-element copies of the
+//     axis-0 two-step route (src/plan.js:375-384, 456-595; twiddle :114-153): the four-step transposes are
+//     folded into the address maps of the two passes (column-tile loads/stores of >= 128 B segments), and
+//     the e^{-2 pi i k1 n2/N} twiddle is fused into pass A's last stage.
+//
+// One workgroup owns a tile of T lines.  Stage 0 reads global memory, the last stage writes global
+// memory, the stages between exchange through LDS.  Thread->(line, butterfly) maps:
+//   ROW map  (lines contiguous in memory):      line = t / TPL, u = t % TPL  -> lanes walk along a line
+//   COL map  (lines are columns, T adjacent):   line = t % T,   u = t / T    -> lanes walk across lines
+// so that every global access is a run of consecutive lanes over consecutive addresses.
+//
+// LDS layouts (bank analysis in DESIGN.md):
+//   COL in + COL out : idx-major  [idx][T]      conflict-free without padding for T >= 16
+//   otherwise        : line-major [line][PITCH] idx padded by idx >> log2(R0); PITCH % 32 == 2 so the
+//                      COL-mapped reads of a ROW-in/COL-out (transposing) kernel are conflict-free.
+#pragma once
+#include "platform.hpp"
+#include "radix.hpp"
+
+namespace mi355 {
+
+enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1 };
+
+struct LineArgs {
+  const cf* in;
+  cf* out;
+  const cf* tw;      // stage tables, concatenated: stage s>=1 is [R_s - 1][Ns_prev] (rows q=1.., k fastest)
+  const cf* tw_lo;   // four-step: W_Ntot^l, l < 2^fs_shift
+  const cf* tw_hi;   // four-step: W_Ntot^(h << fs_shift)
+  long long num_tiles;
+  long long num_lines;   // global lines with G >= num_lines are padding of the last tile: never loaded or stored
+  // ROW side: element p of global line G at G*row_stride + p.
+  // COL side: G -> (o = G / S, i = G % S); element p at o*outer_stride + i + p*S.
+  long long in_S, in_outer_stride;
+  long long out_S, out_outer_stride;
+  float scale;
+  int fs_shift;
+  unsigned fs_lo_mask;
+};
+
+template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_, bool SWAP_IN_, bool SWAP_OUT_, int TWID_>
+struct LineCfg {
+  static constexpr int N = N_, R0 = R0_, R1 = R1_, R2 = R2_, T = T_;
+  static constexpr bool IN_COL = IN_COL_, OUT_COL = OUT_COL_, SWAP_IN = SWAP_IN_, SWAP_OUT = SWAP_OUT_;
+  static constexpr int TWID = TWID_;
+  static_assert(R0 * R1 * R2 == N, "radix product");
+  static constexpr int NSTAGES = (R1 == 1) ? 1 : (R2 == 1 ? 2 : 3);
+  static_assert(R1 > 1 || R2 == 1, "R2 needs R1");
+  static constexpr int RMAX = R0 > R1 ? (R0 > R2 ? R0 : R2) : (R1 > R2 ? R1 : R2);
+  static constexpr int E = RMAX;            // complex values per thread
+  static constexpr int TPL = N / RMAX;      // threads per line
+  static constexpr int THREADS = T * TPL;
+  static constexpr bool IDX_MAJOR = IN_COL && OUT_COL;
+  static constexpr int PADSH = ilog2(R0);
+  static constexpr int PITCH_RAW = N + (N >> PADSH);
+  // PITCH == PMOD (mod 32) complex: COL-mapped ds_read_b64 of a transposing kernel then spreads a 32-lane
+  // group (T lines x 32/T butterflies) over all 64 banks: line step = 2*PMOD dwords, butterfly step = 2
+  static constexpr int PMOD = (!IN_COL && OUT_COL && T <= 32) ? 32 / T : 2;
+  static constexpr int PITCH = ((PITCH_RAW + 31) / 32) * 32 + PMOD;
+  static constexpr int DATA_ELEMS = NSTAGES == 1 ? 0 : (IDX_MAJOR ? N * T : T * PITCH);
+  // stage tables hold rows q = 1..R-1 only (row 0 is all ones): stage 1 [R1-1][R0], stage 2 [R2-1][R0*R1]
+  static constexpr int TW1_ELEMS = NSTAGES >= 2 ? (R1 - 1) * R0 : 0;
+  static constexpr int TW2_ELEMS = NSTAGES == 3 ? (R2 - 1) * R0 * R1 : 0;
+  static constexpr int TW_ELEMS = TW1_ELEMS + TW2_ELEMS;
+  static constexpr int LO_ELEMS = TWID == TWID_FOURSTEP_OUT ? 1024 : 0;
+  static constexpr int LDS_BYTES = (DATA_ELEMS + TW_ELEMS + LO_ELEMS) * 8;
+  // every line lives in one wave and only ROW maps are used: exchanges need no workgroup barrier
+  static constexpr bool WAVE_LOCAL = !IN_COL && !OUT_COL && TPL <= 64 && (64 % TPL) == 0;
+  static_assert(THREADS <= 1024, "workgroup too large");
+  static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
+};
+
+template <class C> MI_DEV int lds_index(int line, int idx) {
+  if constexpr (C::IDX_MAJOR) return idx * C::T + line;
+  else return line * C::PITCH + idx + (idx >> C::PADSH);
+}
+
+template <class C> MI_DEV void lines_sync() {
+  if constexpr (C::WAVE_LOCAL) { MI_WAVE_SYNC(); } else { __syncthreads(); }
+}
+
+// radix / Ns_prev of stage S
+template <class C, int S> struct StageInfo {
+  static constexpr int R = S == 0 ? C::R0 : (S == 1 ? C::R1 : C::R2);
+  static constexpr int NSP = S == 0 ? 1 : (S == 1 ? C::R0 : C::R0 * C::R1);
+  static constexpr int NB = C::E / R;                      // butterflies per thread
+  static constexpr int TW_OFF = S <= 1 ? 0 : C::TW1_ELEMS;  // offset of this stage's table in the LDS copy
+  static constexpr bool FIRST = S == 0;
+  static constexpr bool LAST = S == C::NSTAGES - 1;
+  // thread map: stage 0 follows the input side, every later stage the output side
+  static constexpr bool COLMAP = FIRST ? C::IN_COL : C::OUT_COL;
+};
+
+template <class C, int S> MI_DEV void thread_map(int t, int& line, int& u) {
+  if constexpr (StageInfo<C, S>::COLMAP) { line = t % C::T; u = t / C::T; }
+  else { line = t / C::TPL; u = t % C::TPL; }
+}
+
+// Addressing.  A tile never straddles an outer group (the planner guarantees S % T == 0 on COL sides), so
+// everything tile-dependent is wave-uniform and lives in SGPRs; a lane adds only a 32-bit element offset
+//   voff(line, idx) = line*ls + idx*es      ROW side: ls = row_stride, es = 1;   COL side: ls = 1, es = S
+// and tiles span < 2^32 bytes, which lets the compiler use the saddr + 32-bit voffset load/store forms.
+template <bool COL> MI_DEV long long tile_base(long long G0, long long S, long long outer_stride) {
+  if constexpr (COL) { const long long o = G0 / S; return o * outer_stride + (G0 - o * S); }
+  else return G0 * outer_stride;
+}
+
+template <class C, int S>
+MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, const cf* lds) {
+  using I = StageInfo<C, S>;
+  int line, u; thread_map<C, S>(t, line, u);
+  if constexpr (I::FIRST) {
+    const long long G0 = tile * C::T;
+    const cf* p = a.in + tile_base<C::IN_COL>(G0, a.in_S, a.in_outer_stride);
+    const unsigned ls = C::IN_COL ? 1u : (unsigned)a.in_outer_stride;
+    const unsigned es = C::IN_COL ? (unsigned)a.in_S : 1u;
+    // padding lines of the last tile re-read its last live line (loads stay in bounds, stores are masked)
+    const long long live_lines = a.num_lines - G0;
+    const int lclamp = (long long)line < live_lines ? line : (int)live_lines - 1;
+    const unsigned voff = (unsigned)lclamp * ls + (unsigned)u * es;
+#pragma unroll
+    for (int b = 0; b < I::NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < I::R; ++q) {
+        const cf* pq = p + (unsigned)(b * C::TPL + q * (C::N / I::R)) * es;   // uniform
+        v[b * I::R + q] = cswap_if<C::SWAP_IN>(pq[voff]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int b = 0; b < I::NB; ++b) {
+      const int j = u + b * C::TPL;
+#pragma unroll
+      for (int q = 0; q < I::R; ++q) v[b * I::R + q] = lds[lds_index<C>(line, j + q * (C::N / I::R))];
+    }
+  }
+}
+
+template <class C, int S>
+MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile, int t, cf* lds, const cf* tw_lds, const cf* lo_lds) {
+  using I = StageInfo<C, S>;
+  int line, u; thread_map<C, S>(t, line, u);
+  cf* po = nullptr;
+  unsigned ls = 1, es = 1, gi = 0;
+  bool live = true;
+  if constexpr (I::LAST) {
+    const long long G0 = tile * C::T;
+    po = a.out + tile_base<C::OUT_COL>(G0, a.out_S, a.out_outer_stride);
+    ls = C::OUT_COL ? 1u : (unsigned)a.out_outer_stride;
+    es = C::OUT_COL ? (unsigned)a.out_S : 1u;
+    live = (long long)line < a.num_lines - G0;
+    if constexpr (C::TWID == TWID_FOURSTEP_OUT) gi = (unsigned)(G0 % a.out_S) + (unsigned)line;   // column index n2 of this line
+  }
+#pragma unroll
+  for (int b = 0; b < I::NB; ++b) {
+    const int j = u + b * C::TPL;
+    const int k = j % I::NSP;
+    cf w[I::R];
+#pragma unroll
+    for (int q = 0; q < I::R; ++q) w[q] = v[b * I::R + q];
+    if constexpr (!I::FIRST) {
+#pragma unroll
+      for (int q = 1; q < I::R; ++q) w[q] = cmul(w[q], tw_lds[I::TW_OFF + (q - 1) * I::NSP + k]);
+    }
+    fft_radix<I::R>(w);
+    const int obase_idx = (j / I::NSP) * (I::NSP * I::R) + k;
+#pragma unroll
+    for (int q = 0; q < I::R; ++q) {
+      const int oidx = obase_idx + q * I::NSP;
+      if constexpr (I::LAST) {
+        cf r = w[q];
+        if constexpr (C::TWID == TWID_FOURSTEP_OUT) {
+          // e^{-2 pi i (n2 * k1)/Ntot} = HI[m >> s] * LO[m & mask],  m = n2*k1 < Ntot
+          const unsigned m = gi * (unsigned)oidx;
+          const cf lo = lo_lds[m & a.fs_lo_mask];
+          const cf hi = a.tw_hi[m >> a.fs_shift];
+          r = cmul(r, cmul(hi, lo));
+        }
+        if (a.scale != 1.0f) r = r * a.scale;
+        // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
+        cf* pq = po + (unsigned)(b * C::TPL + q * I::NSP) * es;
+        const unsigned voff = (unsigned)line * ls + (unsigned)u * es;
+        if (live) pq[voff] = cswap_if<C::SWAP_OUT>(r);
+      } else {
+        lds[lds_index<C>(line, oidx)] = w[q];
+      }
+    }
+  }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a) {
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_lds = lds + C::DATA_ELEMS;
+  cf* lo_lds = tw_lds + C::TW_ELEMS;
+  const int t = threadIdx.x;
+
+  // stage tables (and the four-step LO table) -> LDS once per workgroup
+  if constexpr (C::TW_ELEMS > 0) {
+    for (int i = t; i < C::TW_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+  }
+  if constexpr (C::LO_ELEMS > 0) {
+    for (int i = t; i < C::LO_ELEMS; i += C::THREADS) lo_lds[i] = a.tw_lo[i & a.fs_lo_mask];
+  }
+  if constexpr (C::TW_ELEMS > 0 || C::LO_ELEMS > 0) __syncthreads();
+
+  for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    cf v[C::E];
+    stage_read<C, 0>(v, a, tile, t, lds);
+    stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, lo_lds);
+    if constexpr (C::NSTAGES >= 2) {
+      lines_sync<C>();
+      stage_read<C, 1>(v, a, tile, t, lds);
+      lines_sync<C>();
+      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, lo_lds);
+    }
+    if constexpr (C::NSTAGES == 3) {
+      lines_sync<C>();
+      stage_read<C, 2>(v, a, tile, t, lds);
+      lines_sync<C>();
+      stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, lo_lds);
+    }
+  }
+}
+
+}  // namespace mi355

@@ -1,0 +1,561 @@
+// plan.cpp — see plan.hpp.  Pure host C++ (no HIP).
+#include "plan.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace mi355 {
+
+// ---- registry --------------------------------------------------------------------------------------
+namespace {
+constexpr int cmax3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+constexpr int ilog2c(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+LineKernelMeta make_meta(int id, int N, int R0, int R1, int R2, int T, bool ic, bool oc, bool si, bool so, int twid) {
+  // mirrors LineCfg in kern_lines.hpp (checked against the device constants by tests/emu and at library load)
+  LineKernelMeta m{};
+  m.id = id; m.N = N; m.R0 = R0; m.R1 = R1; m.R2 = R2; m.T = T;
+  m.in_col = ic; m.out_col = oc; m.swap_in = si; m.swap_out = so; m.twid = twid;
+  const int nst = R1 == 1 ? 1 : (R2 == 1 ? 2 : 3);
+  const int rmax = cmax3(R0, R1, R2);
+  const int tpl = N / rmax;
+  m.threads = T * tpl;
+  const bool idx_major = ic && oc;
+  const int padsh = ilog2c(R0);
+  const int pitch_raw = N + (N >> padsh);
+  const int pmod = (!ic && oc && T <= 32) ? 32 / T : 2;
+  const int pitch = ((pitch_raw + 31) / 32) * 32 + pmod;
+  const int data = nst == 1 ? 0 : (idx_major ? N * T : T * pitch);
+  const int tw1 = nst >= 2 ? (R1 - 1) * R0 : 0;
+  const int tw2 = nst == 3 ? (R2 - 1) * R0 * R1 : 0;
+  m.tw_elems = tw1 + tw2;
+  const int lo = twid == 1 ? 1024 : 0;
+  m.lds_bytes = (data + m.tw_elems + lo) * 8;
+  return m;
+}
+}  // namespace
+
+const std::vector<LineKernelMeta>& line_kernel_registry() {
+  static const std::vector<LineKernelMeta> reg = [] {
+    std::vector<LineKernelMeta> r;
+    int id = 0;
+#define LINE_ROW(N, R0, R1, R2, T)                                             \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, false, false, 0)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, true, true, 0));
+#define LINE_PASS_A(N, R0, R1, R2, T)                                        \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 1)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 1));
+#define LINE_PASS_B(N, R0, R1, R2, T)                                         \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, false, 0)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, true, 0));
+#include "line_kernels.def"
+#undef LINE_ROW
+#undef LINE_PASS_A
+#undef LINE_PASS_B
+    return r;
+  }();
+  return reg;
+}
+
+const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool swap_in, bool swap_out, int twid) {
+  for (const auto& m : line_kernel_registry())
+    if (m.N == N && m.in_col == in_col && m.out_col == out_col && m.swap_in == swap_in && m.swap_out == swap_out && m.twid == twid)
+      return &m;
+  return nullptr;
+}
+
+PlannerOptions planner_options_from_env() {
+  PlannerOptions o;
+  if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
+  if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
+  return o;
+}
+
+std::vector<int> factorize_radices(int64_t n) {
+  static const int allowed[] = {32, 16, 8, 4, 2, 13, 11, 7, 5, 3};
+  std::vector<int> out;
+  for (int r : allowed)
+    while (n % r == 0 && n > 1) { out.push_back(r); n /= r; }
+  if (n != 1) out.clear();
+  return out;
+}
+
+float2h root_of_unity(int64_t m, int64_t M) {
+  m %= M;
+  if (m < 0) m += M;
+  const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)M;
+  float2h r;
+  r.x = (float)cosl(ang);
+  r.y = (float)sinl(ang);
+  // exact values on the axes (cosl(pi/2) is ~1e-20, harmless, but keep tables clean)
+  if (4 * m == M) { r.x = 0.0f; r.y = -1.0f; }
+  if (2 * m == M) { r.x = -1.0f; r.y = 0.0f; }
+  if (4 * m == 3 * M) { r.x = 0.0f; r.y = 1.0f; }
+  if (m == 0) { r.x = 1.0f; r.y = 0.0f; }
+  return r;
+}
+
+// ---- builder ---------------------------------------------------------------------------------------
+namespace {
+
+bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+int lg2(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; return l; }
+int64_t prodv(const int64_t* s, int rank) { int64_t p = 1; for (int d = 0; d < rank; ++d) p *= s[d]; return p; }
+uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+struct Builder {
+  PlanIR& ir;
+  const PlannerOptions& opt;
+  uint64_t work_top = 0;
+  Builder(PlanIR& i, const PlannerOptions& o) : ir(i), opt(o) {}
+
+  PtrRef alloc_work(uint64_t bytes) {
+    PtrRef r(BUF_WORK, (int64_t)work_top);
+    work_top = align_up(work_top + bytes, 256);
+    if (work_top > ir.work_bytes) ir.work_bytes = work_top;
+    return r;
+  }
+  PtrRef add_table(const std::vector<float2h>& t) {
+    // 256-byte aligned start so LDS staging loads stay aligned
+    while ((ir.table.size() * sizeof(float2h)) % 256 != 0) ir.table.push_back(float2h{0, 0});
+    PtrRef r(BUF_TABLE, (int64_t)(ir.table.size() * sizeof(float2h)));
+    ir.table.insert(ir.table.end(), t.begin(), t.end());
+    return r;
+  }
+  unsigned generic_grid(int64_t total) const {
+    const int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)opt.compute_units * 16;
+    return (unsigned)std::max<int64_t>(1, std::min(blocks, cap));
+  }
+  Step& push(StepKind k) { ir.steps.emplace_back(); ir.steps.back().kind = k; return ir.steps.back(); }
+
+  // stage tables of a line kernel: stage 1 [R1-1][R0] roots of order R0*R1, stage 2 [R2-1][R0*R1] of order N
+  PtrRef line_tables(const LineKernelMeta& m) {
+    std::vector<float2h> t;
+    if (m.R1 > 1) {
+      const int64_t ns = (int64_t)m.R0 * m.R1;
+      for (int q = 1; q < m.R1; ++q) for (int k = 0; k < m.R0; ++k) t.push_back(root_of_unity((int64_t)q * k, ns));
+    }
+    if (m.R2 > 1) {
+      const int64_t nsp = (int64_t)m.R0 * m.R1;
+      for (int q = 1; q < m.R2; ++q) for (int64_t k = 0; k < nsp; ++k) t.push_back(root_of_unity(q * k, m.N));
+    }
+    if (t.empty()) t.push_back(float2h{1, 0});
+    return add_table(t);
+  }
+
+  unsigned lines_grid(const LineKernelMeta& m, int64_t tiles) const {
+    int64_t per_cu = 8;
+    if (m.lds_bytes > 0) per_cu = std::min<int64_t>(per_cu, (160 * 1024) / m.lds_bytes);
+    per_cu = std::min<int64_t>(per_cu, 2048 / m.threads);
+    per_cu = std::max<int64_t>(per_cu, 1);
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, per_cu * opt.compute_units));
+  }
+
+  // batched 1-D FFT along an axis of a dense array: `lines` = S*outer lines of length N, element stride S.
+  //   src/dst may be the same location.  inverse => e^{+...}.  scale fused into the last launch.
+  int emit_axis(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, std::string& err) {
+    const int64_t lines = S * outer;
+    // work buffers taken inside one axis transform are temporaries: released on every exit
+    struct Scope { uint64_t& top; uint64_t mark; ~Scope() { top = mark; } } scope{work_top, work_top};
+    if (N == 1) {
+      if (!src.same(dst)) { Step& c = push(ST_COPY); c.p[0] = src; c.p[1] = dst; c.i[0] = lines * 8; }
+      if (scale != 1.0f) { Step& s = push(ST_SCALE); s.p[0] = dst; s.i[0] = lines * 2; s.f[0] = scale; s.grid = generic_grid(lines * 2); }
+      return MI355FFT_OK;
+    }
+    const bool p2 = is_pow2(N);
+    if (!opt.force_generic && S == 1 && p2 && N <= 4096) {
+      const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
+      if (m) {
+        Step& st = push(ST_LINES);
+        st.variant = m->id;
+        st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m);
+        const int64_t tiles = (lines + m->T - 1) / m->T;
+        st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = N; st.i[4] = 1; st.i[5] = N;
+        st.f[0] = scale;
+        st.grid = lines_grid(*m, tiles);
+        ir.route += "lines[N=" + std::to_string(N) + "] ";
+        return MI355FFT_OK;
+      }
+    }
+    if (!opt.force_generic && S == 1 && p2 && N > 4096) {
+      const int lg = lg2(N);
+      const int64_t N1 = (int64_t)1 << (lg / 2), N2 = N / N1;
+      const LineKernelMeta* ma = find_line_kernel((int)N1, true, true, inverse, false, 1);
+      const LineKernelMeta* mb = find_line_kernel((int)N2, false, true, false, inverse, 0);
+      if (ma && mb && N2 % ma->T == 0 && N1 % mb->T == 0) {
+        int64_t chunk = (int64_t)(opt.chunk_bytes / (uint64_t)(N * 8));
+        chunk = std::max<int64_t>(1, std::min(chunk, lines));
+        const PtrRef w = alloc_work((uint64_t)chunk * N * 8);
+        const PtrRef ta = line_tables(*ma), tb = line_tables(*mb);
+        // four-step roots e^{-2 pi i m/N}, m = n2*k1 < N, as HI[m >> 10] * LO[m & 1023]
+        std::vector<float2h> lo(1024), hi((size_t)(N >> 10));
+        for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
+        for (int64_t h = 0; h < (N >> 10); ++h) hi[(size_t)h] = root_of_unity(h << 10, N);
+        const PtrRef tlo = add_table(lo), thi = add_table(hi);
+        for (int64_t t0 = 0; t0 < lines; t0 += chunk) {
+          const int64_t c = std::min(chunk, lines - t0);
+          Step& a = push(ST_LINES);
+          a.variant = ma->id;
+          a.p[0] = src.plus(t0 * N * 8); a.p[1] = w; a.p[2] = ta; a.p[3] = tlo; a.p[4] = thi;
+          a.i[0] = c * N2 / ma->T; a.i[1] = c * N2; a.i[2] = N2; a.i[3] = N; a.i[4] = N2; a.i[5] = N; a.i[6] = 10; a.i[7] = 1023;
+          a.f[0] = 1.0f;
+          a.grid = lines_grid(*ma, a.i[0]);
+          Step& b = push(ST_LINES);
+          b.variant = mb->id;
+          b.p[0] = w; b.p[1] = dst.plus(t0 * N * 8); b.p[2] = tb;
+          b.i[0] = c * N1 / mb->T; b.i[1] = c * N1; b.i[2] = 1; b.i[3] = N2; b.i[4] = N1; b.i[5] = N;
+          b.f[0] = scale;
+          b.grid = lines_grid(*mb, b.i[0]);
+        }
+        ir.route += "two-pass[N=" + std::to_string(N1) + "x" + std::to_string(N2) + ",chunk=" + std::to_string(chunk) + "] ";
+        return MI355FFT_OK;
+      }
+    }
+    // generic: one global-memory Stockham stage per radix
+    const std::vector<int> radices = factorize_radices(N);
+    if (radices.empty()) {
+      err = "Unsupported: axis length " + std::to_string(N) + " has a prime factor outside {2,3,5,7,11,13} (Bluestein/Rader routes are not built yet)";
+      return MI355FFT_ERR_UNSUPPORTED;
+    }
+    const int ns = (int)radices.size();
+    PtrRef w0, w1;
+    if (ns >= 2) w0 = alloc_work((uint64_t)lines * N * 8);
+    if (ns >= 3) w1 = alloc_work((uint64_t)lines * N * 8);
+    int64_t nsp = 1;
+    PtrRef cur = src;
+    for (int s = 0; s < ns; ++s) {
+      const int R = radices[s];
+      const bool last = s == ns - 1;
+      PtrRef to = last ? dst : ((s % 2 == 0) ? w0 : w1);
+      std::vector<float2h> t;
+      if (nsp > 1) {
+        t.resize((size_t)(R * nsp));
+        for (int q = 0; q < R; ++q) for (int64_t k = 0; k < nsp; ++k) t[(size_t)(q * nsp + k)] = root_of_unity(q * k, nsp * R);
+      } else t.push_back(float2h{1, 0});
+      Step& st = push(ST_STAGE);
+      st.variant = R;
+      st.p[0] = cur; st.p[1] = to; st.p[2] = add_table(t);
+      st.i[0] = lines * (N / R); st.i[1] = N; st.i[2] = S; st.i[3] = nsp;
+      st.i[4] = (inverse && s == 0) ? 1 : 0; st.i[5] = (inverse && last) ? 1 : 0;
+      st.f[0] = last ? scale : 1.0f;
+      st.grid = generic_grid(st.i[0]);
+      cur = to;
+      nsp *= R;
+    }
+    ir.route += "stages[N=" + std::to_string(N) + ",S=" + std::to_string(S) + ",n=" + std::to_string(ns) + "] ";
+    return MI355FFT_OK;
+  }
+
+  // all axes of a dense [batch][shape] complex array, src -> dst
+  int emit_nd(PtrRef src, PtrRef dst, const int64_t* shape, int rank, int64_t batch, bool inverse, float scale, std::string& err,
+              int first_axis = 0) {
+    PtrRef cur = src;
+    int64_t S = 1;
+    for (int a = 0; a < first_axis; ++a) S *= shape[a];
+    const int64_t total = prodv(shape, rank);
+    bool any = false;
+    int last_axis = -1;
+    for (int a = first_axis; a < rank; ++a) if (shape[a] > 1) last_axis = a;
+    for (int a = first_axis; a < rank; ++a) {
+      const int64_t N = shape[a];
+      if (N > 1) {
+        const int64_t outer = batch * (total / (S * N));
+        const int rc = emit_axis(cur, dst, N, S, outer, inverse, a == last_axis ? scale : 1.0f, err);
+        if (rc) return rc;
+        cur = dst;
+        any = true;
+      }
+      S *= N;
+    }
+    if (!any) return emit_axis(cur, dst, 1, 1, batch * total, inverse, scale, err);
+    return MI355FFT_OK;
+  }
+
+  void emit_strided(bool gather, PtrRef phys, PtrRef dense, const mi355fft_side_layout& lay, const int64_t* shape, int rank, int64_t batch,
+                    const int64_t* dense_shape, const int64_t* dense_sub_offset, int64_t dense_batch_stride, int64_t extra_phys_offset) {
+    Step& st = push(gather ? ST_GATHER : ST_SCATTER);
+    st.p[0] = gather ? phys : dense;
+    st.p[1] = gather ? dense : phys;
+    const int64_t per = prodv(shape, rank);
+    st.i[0] = batch * per; st.i[1] = per; st.i[2] = rank;
+    int64_t dstride = 1, doff = 0, pstride = 1;
+    for (int d = 0; d < rank; ++d) {
+      st.shape[d] = shape[d];
+      st.sa[d] = lay.strided ? lay.strides[d] : pstride;
+      st.sb[d] = dstride;
+      doff += (dense_sub_offset ? dense_sub_offset[d] : 0) * dstride;
+      dstride *= dense_shape[d];
+      pstride *= shape[d];
+    }
+    st.i[3] = (lay.strided ? lay.offset_elements : 0) + extra_phys_offset;
+    st.i[4] = (lay.strided && lay.batch_stride_elements > 0) ? lay.batch_stride_elements : per;
+    st.i[5] = doff;
+    st.i[6] = dense_batch_stride;
+    st.grid = generic_grid(st.i[0]);
+  }
+};
+
+double scale_factor(int normalize, bool inverse, double n_total) {  // runtime/common.js:35-40
+  if (normalize == MI355FFT_NORM_NONE) return 1.0;
+  if (normalize == MI355FFT_NORM_UNITARY) return 1.0 / std::sqrt(n_total);
+  return inverse ? 1.0 / n_total : 1.0;
+}
+
+// bytes a strided side must cover: offset + (batch-1)*batchStride + sum (shape_d-1)*stride_d + 1 elements
+// (runtime/tensor_descriptor.js:113-121)
+uint64_t strided_extent_elems(const mi355fft_side_layout& l, const int64_t* shape, int rank, int64_t batch, int64_t extra) {
+  int64_t last = l.offset_elements + extra + (batch - 1) * (l.batch_stride_elements > 0 ? l.batch_stride_elements : prodv(shape, rank));
+  for (int d = 0; d < rank; ++d) last += (shape[d] - 1) * l.strides[d];
+  return (uint64_t)(last + 1);
+}
+
+int validate_common(const mi355fft_plan_desc& d, std::string& err) {
+  if (d.struct_size != sizeof(mi355fft_plan_desc)) { err = "mi355fft_plan_desc.struct_size mismatch (ABI)"; return MI355FFT_ERR_INVALID; }
+  if (d.rank < 1 || d.rank > MI355FFT_MAX_RANK) { err = "shape must be an array of one or more positive dimensions"; return MI355FFT_ERR_INVALID; }
+  for (int i = 0; i < d.rank; ++i)
+    if (d.shape[i] <= 0) { err = "shape elements must be positive ints"; return MI355FFT_ERR_INVALID; }
+  if (d.batch <= 0) { err = "batch must be positive int; got " + std::to_string(d.batch); return MI355FFT_ERR_INVALID; }
+  if (d.normalize < 0 || d.normalize > 2) { err = "normalize must be one of \"none\", \"backward\", \"unitary\""; return MI355FFT_ERR_INVALID; }
+  if (prodv(d.shape, d.rank) * d.batch > ((int64_t)1 << 40)) { err = "Unsupported: more than 2^40 points in one plan"; return MI355FFT_ERR_UNSUPPORTED; }
+  for (const mi355fft_side_layout* l : {&d.input, &d.output})
+    if (l->strided)
+      for (int i = 0; i < d.rank; ++i)
+        if (l->strides[i] <= 0) { err = "layout strides must be positive ints"; return MI355FFT_ERR_INVALID; }
+  return MI355FFT_OK;
+}
+
+int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (d.direction != MI355FFT_FORWARD && d.direction != MI355FFT_INVERSE) { err = "direction must be one of \"forward\", \"inverse\""; return MI355FFT_ERR_INVALID; }
+  const bool inverse = d.direction == MI355FFT_INVERSE;
+  const int64_t n = prodv(d.shape, d.rank);
+  const float scale = (float)scale_factor(d.normalize, inverse, (double)n);
+  PtrRef in(BUF_INPUT, 0), out(d.in_place ? BUF_INPUT : BUF_OUTPUT, 0);
+  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, d.shape, d.rank, d.batch, 0) * 8 : (uint64_t)n * d.batch * 8;
+  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, d.shape, d.rank, d.batch, 0) * 8 : (uint64_t)n * d.batch * 8;
+  PtrRef src = in, dst = out;
+  if (d.input.strided) {
+    src = b.alloc_work((uint64_t)n * d.batch * 8);
+    b.emit_strided(true, in, src, d.input, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0);
+    b.ir.route += "gather ";
+  }
+  if (d.output.strided) dst = d.input.strided ? src : b.alloc_work((uint64_t)n * d.batch * 8);
+  const int rc = b.emit_nd(src, dst, d.shape, d.rank, d.batch, inverse, scale, err);
+  if (rc) return rc;
+  if (d.output.strided) {
+    b.emit_strided(false, out, dst, d.output, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0);
+    b.ir.route += "scatter ";
+  }
+  return MI355FFT_OK;
+}
+
+// r2c along axis 0 (packed P = N/2+1 bins), then c2c along the remaining axes of the packed array
+int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (d.direction != MI355FFT_FORWARD) { err = "r2c supports direction:\"forward\" only"; return MI355FFT_ERR_INVALID; }
+  if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
+  if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on r2c are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
+  const int64_t N = d.shape[0], P = N / 2 + 1;
+  if (N < 2) { err = "r2c requires shape[0] >= 2"; return MI355FFT_ERR_INVALID; }
+  const int64_t n = prodv(d.shape, d.rank), lines = d.batch * (n / N);
+  const float scale = (float)scale_factor(d.normalize, false, (double)n);
+  PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
+  b.ir.in_bytes = (uint64_t)n * d.batch * 4;
+  b.ir.out_bytes = (uint64_t)lines * P * 8;
+  if (N % 2 == 0) {
+    const int64_t H = N / 2;
+    PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
+    // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]
+    int rc = b.emit_axis(in, z, H, 1, lines, false, 1.0f, err);
+    if (rc) return rc;
+    std::vector<float2h> tw((size_t)(H + 1));
+    for (int64_t k = 0; k <= H; ++k) tw[(size_t)k] = root_of_unity(k, N);
+    Step& st = b.push(ST_R2C_POST);
+    st.p[0] = z; st.p[1] = out; st.p[2] = b.add_table(tw);
+    st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
+    st.grid = b.generic_grid(lines * P);
+    b.ir.route += "r2c-split ";
+  } else {
+    PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
+    Step& e = b.push(ST_REAL_TO_COMPLEX);
+    e.p[0] = in; e.p[1] = full; e.i[0] = lines * N; e.grid = b.generic_grid(lines * N);
+    int rc = b.emit_axis(full, full, N, 1, lines, false, 1.0f, err);
+    if (rc) return rc;
+    Step& p = b.push(ST_PACK_HALF);
+    p.p[0] = full; p.p[1] = out; p.i[0] = N; p.i[1] = P; p.i[2] = lines; p.i[3] = P; p.f[0] = scale;
+    p.grid = b.generic_grid(lines * P);
+    b.ir.route += "r2c-full ";
+  }
+  if (d.rank > 1) {
+    int64_t ps[MI355FFT_MAX_RANK];
+    for (int i = 0; i < d.rank; ++i) ps[i] = d.shape[i];
+    ps[0] = P;
+    return b.emit_nd(out, out, ps, d.rank, d.batch, false, 1.0f, err, 1);
+  }
+  return MI355FFT_OK;
+}
+
+int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (d.direction != MI355FFT_INVERSE) { err = "c2r supports direction:\"inverse\" only"; return MI355FFT_ERR_INVALID; }
+  if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
+  if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on c2r are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
+  const int64_t N = d.shape[0], P = N / 2 + 1;
+  if (N < 2) { err = "c2r requires shape[0] >= 2"; return MI355FFT_ERR_INVALID; }
+  const int64_t n = prodv(d.shape, d.rank), lines = d.batch * (n / N);
+  const float scale = (float)scale_factor(d.normalize, true, (double)n);
+  PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
+  b.ir.in_bytes = (uint64_t)lines * P * 8;
+  b.ir.out_bytes = (uint64_t)n * d.batch * 4;
+  PtrRef packed = in;
+  if (d.rank > 1) {
+    // inverse c2c over axes 1.. of the packed spectrum; the caller's input is not modified
+    packed = b.alloc_work((uint64_t)lines * P * 8);
+    int64_t ps[MI355FFT_MAX_RANK];
+    for (int i = 0; i < d.rank; ++i) ps[i] = d.shape[i];
+    ps[0] = P;
+    Step& c = b.push(ST_COPY);
+    c.p[0] = in; c.p[1] = packed; c.i[0] = lines * P * 8;
+    int rc = b.emit_nd(packed, packed, ps, d.rank, d.batch, true, 1.0f, err, 1);
+    if (rc) return rc;
+  }
+  if (N % 2 == 0) {
+    const int64_t H = N / 2;
+    PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
+    std::vector<float2h> tw((size_t)(H + 1));
+    for (int64_t k = 0; k <= H; ++k) tw[(size_t)k] = root_of_unity(k, N);
+    Step& st = b.push(ST_C2R_PRE);
+    st.p[0] = packed; st.p[1] = z; st.p[2] = b.add_table(tw);
+    st.i[0] = H; st.i[1] = lines; st.i[2] = P;
+    st.grid = b.generic_grid(lines * H);
+    // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
+    int rc = b.emit_axis(z, out, H, 1, lines, true, scale, err);
+    if (rc) return rc;
+    b.ir.route += "c2r-split ";
+  } else {
+    PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
+    Step& u = b.push(ST_UNPACK_HERM);
+    u.p[0] = packed; u.p[1] = full; u.i[0] = N; u.i[1] = P; u.i[2] = lines; u.i[3] = P;
+    u.grid = b.generic_grid(lines * N);
+    int rc = b.emit_axis(full, full, N, 1, lines, true, 1.0f, err);
+    if (rc) return rc;
+    Step& r = b.push(ST_COMPLEX_TO_REAL);
+    r.p[0] = full; r.p[1] = out; r.i[0] = lines * N; r.f[0] = scale;
+    r.grid = b.generic_grid(lines * N);
+    b.ir.route += "c2r-full ";
+  }
+  return MI355FFT_OK;
+}
+
+// y_k = IFFT( FFT(x) .* (conj?)FFT(h_k) ) / Nfft, cropped per boundary, written per output layout / lanes
+// (runtime/plans/fftconv.js:308-709, exec :1415-1712; reference semantics: src/utils/math.js:469-603)
+int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (d.in_place) { err = "fftconv inPlace=true is not supported in current implementation"; return MI355FFT_ERR_INVALID; }
+  if (d.conv_mode != MI355FFT_CONVOLUTION && d.conv_mode != MI355FFT_CORRELATION) { err = "fftConv.mode must be one of \"convolution\", \"correlation\""; return MI355FFT_ERR_INVALID; }
+  if (d.conv_boundary < 0 || d.conv_boundary > 3) { err = "fftConv.boundary must be one of \"circular\", \"linear-full\", \"linear-same\", \"linear-valid\""; return MI355FFT_ERR_INVALID; }
+  if (d.conv_kernel_count <= 0) { err = "fftConv.kernelCount must be a positive integer; got " + std::to_string(d.conv_kernel_count); return MI355FFT_ERR_INVALID; }
+  const int rank = d.rank;
+  const int64_t K = d.conv_kernel_count, B = d.batch;
+  int64_t ks[8], fs[8], os[8], ooff[8], zero[8] = {0};
+  bool ks_given = false;
+  for (int i = 0; i < rank; ++i) if (d.conv_kernel_shape[i] != 0) ks_given = true;
+  for (int i = 0; i < rank; ++i) {
+    ks[i] = ks_given ? d.conv_kernel_shape[i] : d.shape[i];
+    if (ks[i] <= 0) { err = "fftConv.kernelShape must be an array of " + std::to_string(rank) + " positive ints"; return MI355FFT_ERR_INVALID; }
+    if (d.conv_boundary == MI355FFT_CIRCULAR) {
+      if (ks[i] > d.shape[i]) { err = "fftConv.kernelShape[" + std::to_string(i) + "] must be <= shape[" + std::to_string(i) + "] when fftConv.boundary=\"circular\""; return MI355FFT_ERR_INVALID; }
+      fs[i] = d.shape[i]; os[i] = d.shape[i]; ooff[i] = 0;
+    } else {
+      fs[i] = d.shape[i] + ks[i] - 1;
+      if (d.conv_boundary == MI355FFT_LINEAR_FULL) { os[i] = fs[i]; ooff[i] = 0; }
+      else if (d.conv_boundary == MI355FFT_LINEAR_SAME) { os[i] = d.shape[i]; ooff[i] = (ks[i] - 1) / 2; }
+      else {
+        os[i] = d.shape[i] - ks[i] + 1; ooff[i] = ks[i] - 1;
+        if (os[i] <= 0) { err = "fftConv.boundary=\"linear-valid\" requires kernelShape[" + std::to_string(i) + "] <= shape[" + std::to_string(i) + "]"; return MI355FFT_ERR_INVALID; }
+      }
+    }
+  }
+  const int64_t inN = prodv(d.shape, rank), kN = prodv(ks, rank), fN = prodv(fs, rank), oN = prodv(os, rank);
+  PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0), kern(BUF_KERNEL, 0);
+  b.ir.kernel_bytes = (uint64_t)K * kN * 8;
+  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, d.shape, rank, B, 0) * 8 : (uint64_t)inN * B * 8;
+  const int64_t kstride = d.conv_output_kernel_stride_elements;
+  if (d.output.strided) {
+    if (K > 1 && kstride <= 0) { err = "multi-kernel strided output requires fftConv.channelPolicy.output or fftConv.outputKernelStrideElements"; return MI355FFT_ERR_INVALID; }
+    b.ir.out_bytes = strided_extent_elems(d.output, os, rank, B, (K - 1) * kstride) * 8;
+  } else b.ir.out_bytes = (uint64_t)K * B * oN * 8;
+
+  const bool embed = d.conv_boundary != MI355FFT_CIRCULAR;
+  mi355fft_side_layout dense{};  // strided == 0
+  // 1. kernels: zero-padded into the FFT domain, transformed once per exec
+  PtrRef kf = b.alloc_work((uint64_t)K * fN * 8);
+  bool kernel_embed = false;
+  for (int i = 0; i < rank; ++i) if (ks[i] != fs[i]) kernel_embed = true;
+  if (kernel_embed) {
+    Step& z = b.push(ST_ZERO); z.p[0] = kf; z.i[0] = K * fN * 2; z.grid = b.generic_grid(K * fN * 2);
+    b.emit_strided(true, kern, kf, dense, ks, rank, K, fs, zero, fN, 0);
+  } else {
+    Step& c = b.push(ST_COPY); c.p[0] = kern; c.p[1] = kf; c.i[0] = K * fN * 8;
+  }
+  int rc = b.emit_nd(kf, kf, fs, rank, K, false, 1.0f, err);
+  if (rc) return rc;
+  // 2. data: gather (strided lanes) / embed (linear modes) into the dense FFT domain, forward transform once
+  PtrRef xf = b.alloc_work((uint64_t)B * fN * 8);
+  if (embed) { Step& z = b.push(ST_ZERO); z.p[0] = xf; z.i[0] = B * fN * 2; z.grid = b.generic_grid(B * fN * 2); }
+  if (embed || d.input.strided) b.emit_strided(true, in, xf, d.input, d.shape, rank, B, fs, zero, fN, 0);
+  rc = b.emit_nd((embed || d.input.strided) ? xf : in, xf, fs, rank, B, false, 1.0f, err);
+  if (rc) return rc;
+  // 3. per kernel: product, inverse transform scaled by 1/Nfft, crop + place
+  PtrRef y = b.alloc_work((uint64_t)B * fN * 8);
+  const float inv_n = (float)(1.0 / (double)fN);
+  const bool direct_out = !embed && !d.output.strided;   // the inverse FFT can land in the output itself
+  for (int64_t k = 0; k < K; ++k) {
+    Step& pm = b.push(ST_POINTWISE);
+    pm.p[0] = xf; pm.p[1] = y; pm.p[2] = kf.plus(k * fN * 8);
+    pm.i[0] = fN; pm.i[1] = B * fN; pm.i[2] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; pm.f[0] = 1.0f;
+    pm.grid = b.generic_grid(B * fN);
+    if (direct_out && d.conv_output_layout == MI355FFT_KERNEL_MAJOR) {
+      rc = b.emit_nd(y, out.plus(k * B * oN * 8), fs, rank, B, true, inv_n, err);
+      if (rc) return rc;
+      continue;
+    }
+    rc = b.emit_nd(y, y, fs, rank, B, true, inv_n, err);
+    if (rc) return rc;
+    if (d.output.strided) {
+      // lane of kernel k: outputOffset + k*kernelStride + b*batchStride (fftconv.js:868-871)
+      b.emit_strided(false, out, y, d.output, os, rank, B, fs, ooff, fN, k * kstride);
+    } else {
+      mi355fft_side_layout ol{};
+      ol.strided = 1;
+      int64_t st = 1;
+      for (int i = 0; i < rank; ++i) { ol.strides[i] = st; st *= os[i]; }
+      if (d.conv_output_layout == MI355FFT_KERNEL_MAJOR) { ol.offset_elements = k * B * oN; ol.batch_stride_elements = oN; }
+      else { ol.offset_elements = k * oN; ol.batch_stride_elements = K * oN; }
+      b.emit_strided(false, out, y, ol, os, rank, B, fs, ooff, fN, 0);
+    }
+  }
+  b.ir.route += "fftconv[K=" + std::to_string(K) + "] ";
+  return MI355FFT_OK;
+}
+
+}  // namespace
+
+int build_plan(const mi355fft_plan_desc& desc, const PlannerOptions& opt, PlanIR& out, std::string& err) {
+  out = PlanIR();
+  out.desc = desc;
+  int rc = validate_common(desc, err);
+  if (rc) return rc;
+  Builder b(out, opt);
+  switch (desc.type) {
+    case MI355FFT_C2C: rc = build_c2c(desc, b, err); break;
+    case MI355FFT_R2C: rc = build_r2c(desc, b, err); break;
+    case MI355FFT_C2R: rc = build_c2r(desc, b, err); break;
+    case MI355FFT_FFTCONV: rc = build_fftconv(desc, b, err); break;
+    default: err = "type must be one of \"c2c\", \"r2c\", \"c2r\", \"fftconv\" (other createPlan types are outside the MI355X hot path)"; rc = MI355FFT_ERR_UNSUPPORTED;
+  }
+  if (rc) return rc;
+  if (out.table.empty()) out.table.push_back(float2h{1, 0});
+  return MI355FFT_OK;
+}
+
+}  // namespace mi355

@@ -1,0 +1,87 @@
+// plan.hpp — host-side planner: turns a createPlan option block into a list of kernel launches.
+//
+// Replaces the reference's runtime planners for the hot path:
+//   src/runtime/plans/c2c.js  (C2CPlan ctor :533-1229, exec :3607-4211)   -> build_c2c
+//   src/runtime/plans/r2c.js  (:52-512, core :1518-1557)                  -> build_r2c
+//   src/runtime/plans/c2r.js  (:146-, core :1743-1763)                    -> build_c2r
+//   src/runtime/plans/fftconv.js (:308-709, exec :1415-1712)              -> build_fftconv
+//   src/plan.js factorizeRadices (:20-33) / createFftPlan (:1298-1512)    -> emit_axis + radix factoring
+// The reference's ~75 % of planner code that works around WebGPU binding/buffer limits (large_policy,
+// segmented_io, BufferView windows) has no counterpart: one HIP allocation spans 288 GB.
+//
+// This file has no HIP dependency: the same planner drives the HIP launcher (api.hip) and the host
+// emulation used by the CPU tests (tests/emu).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355fft.h"
+
+namespace mi355 {
+
+struct float2h { float x, y; };
+
+struct LineKernelMeta {
+  int id;
+  int N, R0, R1, R2, T;
+  bool in_col, out_col, swap_in, swap_out;
+  int twid;
+  int threads, lds_bytes, tw_elems;
+};
+const std::vector<LineKernelMeta>& line_kernel_registry();
+const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool swap_in, bool swap_out, int twid);
+
+enum BufId : int { BUF_NONE = -1, BUF_INPUT = 0, BUF_OUTPUT = 1, BUF_WORK = 2, BUF_KERNEL = 3, BUF_TABLE = 4 };
+struct PtrRef {
+  int buf = BUF_NONE;
+  int64_t off = 0;  // bytes
+  PtrRef() {}
+  PtrRef(int b, int64_t o) : buf(b), off(o) {}
+  PtrRef plus(int64_t bytes) const { return PtrRef(buf, off + bytes); }
+  bool same(const PtrRef& o) const { return buf == o.buf && off == o.off; }
+};
+
+enum StepKind : int {
+  ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE
+};
+
+// One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).
+struct Step {
+  StepKind kind;
+  int variant = 0;           // ST_LINES: registry id; ST_STAGE: radix
+  PtrRef p[5];               // kind-specific pointer slots
+  int64_t i[12] = {0};     // kind-specific integers
+  float f[2] = {1.0f, 1.0f}; // kind-specific floats
+  int64_t shape[8] = {0}, sa[8] = {0}, sb[8] = {0};  // ST_GATHER / ST_SCATTER
+  unsigned grid = 1;
+};
+
+struct PlanIR {
+  mi355fft_plan_desc desc;
+  std::vector<Step> steps;
+  std::vector<float2h> table;     // all twiddle tables, uploaded once at plan creation
+  uint64_t work_bytes = 0;        // plan.getWorkspaceSizeBytes()
+  uint64_t in_bytes = 0, out_bytes = 0, kernel_bytes = 0;  // minimum extents the exec buffers must cover
+  std::string route;              // human-readable route description (plan_describe)
+};
+
+struct PlannerOptions {
+  uint64_t chunk_bytes = 64ull << 20;  // two-pass: bytes of inter-pass intermediate kept hot in Infinity Cache
+  int compute_units = 256;
+  int force_generic = 0;               // tests: route everything through the global-memory stage kernels
+};
+PlannerOptions planner_options_from_env();
+
+// returns MI355FFT_OK or an error status with `err` filled (message style follows the reference's throws)
+int build_plan(const mi355fft_plan_desc& desc, const PlannerOptions& opt, PlanIR& out, std::string& err);
+
+// radix factorisation of the generic route: greedy largest-first over {32,16,8,4,2,13,11,7,5,3}
+// (superset of src/plan.js:20-33's {13,11,8,7,5,4,3,2}); empty when n has another prime factor
+std::vector<int> factorize_radices(int64_t n);
+
+// e^{-2 pi i m / M} rounded to f32 from an 80-bit evaluation
+float2h root_of_unity(int64_t m, int64_t M);
+
+}  // namespace mi355

@@ -1,0 +1,46 @@
+// platform.hpp — the one include every kernel header uses.
+//
+// Product build (hipcc, --offload-arch=gfx950): pulls in the HIP runtime.
+//
+// MI355_HOST_EMU build (tests only, tests/emu/): the SAME kernel sources are compiled as plain C++ for the
+// host so that index math, LDS layouts and barrier placement can be unit-tested, and run under
+// ASan/UBSan, in the GPU-less build container.  One std::thread per GPU thread, a pthread barrier for
+// __syncthreads().  It is a test harness: nothing in libmi355fft.so or the addon is built from it and
+// there is no runtime fallback to it (api.hip fails loudly when no HIP device is present).
+#pragma once
+
+#ifndef MI355_HOST_EMU
+#include <hip/hip_runtime.h>
+#define MI_SMEM_DECL(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MI_SMEM_DECL_STATIC(type, name, n) __shared__ type name[n]
+#define MI_WAVE_SYNC()                                       \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+  } while (0)
+#else
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+namespace emu {
+struct dim3_t { unsigned x = 1, y = 1, z = 1; };
+extern thread_local dim3_t t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
+extern thread_local char* t_smem;
+void sync_threads();
+}  // namespace emu
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__
+#define threadIdx (emu::t_threadIdx)
+#define blockIdx (emu::t_blockIdx)
+#define blockDim (emu::t_blockDim)
+#define gridDim (emu::t_gridDim)
+#define __syncthreads() emu::sync_threads()
+#define MI_SMEM_DECL(name) char* name = emu::t_smem
+#define MI_SMEM_DECL_STATIC(type, name, n) type* name = reinterpret_cast<type*>(emu::t_smem)
+#define MI_WAVE_SYNC() emu::sync_threads() /* emulated waves are not lock-step: use the block barrier */
+#endif
