@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: batched 1-D c2c f32, N=2^20, batch=4096 per GPU (BASELINE.json config 3).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--no-graph] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (plan.exec recorded once into a command list, replayed per step) over
+one batch of synthetic complex input already resident in HBM (device-side twin of the oracle's seeded PRNG,
+components uniform in (-0.5, 0.5) as math.js:150-158).  One process per GPU; ranks shard the batch dimension
+(rank r owns transforms [r*B, (r+1)*B)), no data-path collective — torch.distributed (RCCL)
+only brackets the timed region with barriers and reduces the elapsed time with MAX.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "webgpu-fft_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+WORKLOADS = {
+    # name: (type, N, batch per GPU, algorithmic bytes per point, description)
+    "c2c_2p20_b4096": ("c2c", 1 << 20, 4096, 16, "1D c2c N=2^20 batch=4096 f32 forward, out-of-place (BASELINE config 3, north-star metric)"),
+    "c2c_1024_b65536": ("c2c", 1024, 65536, 16, "1D c2c N=1024 batch=65536 f32 forward, out-of-place (BASELINE config 2)"),
+    "c2c_2p20_b512": ("c2c", 1 << 20, 512, 16, "1D c2c N=2^20 batch=512 (reduced batch; NOT the headline config)"),
+    "r2c_2p22_b1024": ("r2c", 1 << 22, 1024, 8, "1D r2c N=2^22, 1024 transforms per GPU (BASELINE config 5 shard)"),
+}
+
+
+class HipEvents:
+    """hipEvent timing on the library's own stream (torch.cuda.Event would only see torch's stream)."""
+
+    def __init__(self):
+        self.hip = None
+        for name in ("libamdhip64.so.7", "libamdhip64.so"):
+            try:
+                self.hip = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if self.hip is None:
+            raise RuntimeError("libamdhip64 not loadable")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [ctypes.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+
+    def create(self):
+        e = ctypes.c_void_p()
+        rc = self.hip.hipEventCreate(ctypes.byref(e))
+        if rc != 0:
+            raise RuntimeError(f"hipEventCreate failed: {rc}")
+        return e
+
+    def record(self, ev, stream):
+        rc = self.hip.hipEventRecord(ev, stream)
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed: {rc}")
+
+    def elapsed_ms(self, a, b):
+        self.hip.hipEventSynchronize(b)
+        ms = ctypes.c_float()
+        rc = self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b)
+        if rc != 0:
+            raise RuntimeError(f"hipEventElapsedTime failed: {rc}")
+        return float(ms.value)
+
+
+def cpu_baseline(n, seconds_target=12.0):
+    """the oracle (C restatement of math.js:25-88, kind "port") on the host cores, bounded sample"""
+    import numpy as np
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    if n >= (1 << 16):
+        sample = max(threads, 32)
+    else:
+        sample = max(threads * 64, 4096)
+    x = orc.random_complex_batch(n, min(sample, 64), 0x5EED00C0).reshape(-1)
+    reps = sample // min(sample, 64)
+    x = np.tile(x, reps)
+    sample = x.size // (2 * n)
+    t0 = time.perf_counter()
+    orc.fft1d_ref_batch(x, n, sample, "forward", nthreads=threads)
+    dt = time.perf_counter() - t0
+    rounds = 1
+    # repeat the same sample until ~seconds_target of CPU work has been timed
+    extra = int(min(max(seconds_target / max(dt, 1e-6) - 1, 0), 200))
+    t1 = time.perf_counter()
+    for _ in range(extra):
+        orc.fft1d_ref_batch(x, n, sample, "forward", nthreads=threads)
+    dt_total = dt + (time.perf_counter() - t1)
+    rounds += extra
+    pts = float(n) * sample * rounds
+    return {"value": pts / dt_total / 1e9, "unit": "GPoints/s", "cores": threads, "kind": "port",
+            "sample": f"{sample} transforms of N={n} x {rounds} rounds in {dt_total:.1f}s, oracle/oracle.c fft1d_ref (radix-2, f32 storage, f64 twiddles), {threads} pthreads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default=os.environ.get("MI355FFT_BENCH_WORKLOAD", "c2c_2p20_b4096"))
+    ap.add_argument("--no-graph", action="store_true", help="replay the op list instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch  # first: its bundled HIP runtime is the one the library then binds to
+    import torch.distributed as dist
+    use_dist = world > 1
+    if use_dist:
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import mi355fft
+    typ, n, batch, bytes_per_point, desc = WORKLOADS[args.workload]
+    dev = mi355fft.Device(local_rank, use_graph=not args.no_graph)
+    info = dev.info()
+    if typ == "c2c":
+        in_bytes = out_bytes = n * batch * 8
+        in_row_floats = 2 * n
+        opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+    else:
+        in_bytes, out_bytes = n * batch * 4, (n // 2 + 1) * batch * 8
+        in_row_floats = n
+        opts = {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+    need = in_bytes + out_bytes + (1 << 30)
+    if info["hbm_free"] < need:
+        raise SystemExit(f"workload {args.workload} needs {need >> 30} GiB of HBM, {info['hbm_free'] >> 30} GiB free")
+
+    inp = dev.createBuffer({"size": in_bytes})
+    out = dev.createBuffer({"size": out_bytes})
+    # synthetic input, generated on the device: transform b of rank r is stream (seed0, r*batch + b)
+    dev.fillRandom(inp, 0, in_row_floats, batch, 0x5EED0003, rank * batch)
+    plan = mi355fft.createPlan(dev, opts)
+    route, launches = plan.describe()
+    enc = dev.createCommandEncoder()
+    plan.exec(enc, {"input": inp, "output": out})
+    cmds = enc.finish()
+    ev = HipEvents()
+    e0, e1 = ev.create(), ev.create()
+
+    def barrier():
+        dev.queue.onSubmittedWorkDone()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        dev.queue.submit([cmds])
+    barrier()
+    t0 = time.perf_counter()
+    ev.record(e0, dev.stream)
+    for _ in range(args.steps):
+        dev.queue.submit([cmds])
+    ev.record(e1, dev.stream)
+    dev.queue.onSubmittedWorkDone()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev.elapsed_ms(e0, e1)
+    barrier()
+
+    # MAX over ranks of the wall time around the K steps (and of the device-event time)
+    times = torch.tensor([wall, dev_ms / 1e3], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if use_dist:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    wall_max, dev_max = float(times[0]), float(times[1])
+
+    if rank == 0:
+        points_per_step = float(n) * batch * world
+        ms_per_step = wall_max / args.steps * 1e3
+        value = points_per_step / (wall_max / args.steps) / 1e9
+        # roofline of the transform on ONE GPU: algorithmic bytes of a step / device time of a step (hip events)
+        step_dev_s = dev_max / args.steps
+        achieved = bytes_per_point * float(n) * batch / step_dev_s / 1e9
+        line = {
+            "metric": "1D c2c f32 GPoints/s at N=2^20 batch=4096" if args.workload == "c2c_2p20_b4096" else f"GPoints/s ({args.workload})",
+            "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (device-side seeded PRNG twin of the oracle, uniform (-0.5,0.5), resident in HBM)",
+            "config": {"workload": desc, "type": typ, "N": n, "batch_per_gpu": batch, "global_batch": batch * world,
+                       "sharding": f"batch-sharded x{world}, no data-path collective", "route": route.strip(),
+                       "launches_per_step": launches, "executor": "op-list replay" if args.no_graph else "hipGraph replay",
+                       "arch": info["arch"], "compute_units": info["compute_units"]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "kernel": "fft_lines_kernel (pass A + pass B per chunk)" if "two-pass" in route else "fft_lines_kernel",
+                         "algorithmic_bytes_per_point": bytes_per_point, "device_ms_per_step": step_dev_s * 1e3,
+                         "avg_launch_us": step_dev_s * 1e6 / max(launches, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(n)
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
+                line["cpu_baseline"] = {"value": None, "unit": "GPoints/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+
+    cmds.release()
+    plan.destroy()
+    inp.destroy()
+    out.destroy()
+    dev.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

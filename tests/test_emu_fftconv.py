@@ -1,0 +1,145 @@
+"""CPU tier: fftconv plans (planner + kernels under host emulation) against the reference's fftConvRef
+fixtures (tests/golden, generated from src/utils/math.js:469-603) and the oracle, including the
+channel-lane sentinel test that mirrors test/complete.suite.js:4715-4836."""
+import os
+
+import numpy as np
+import pytest
+
+import emu_harness as emu
+from conftest import GOLDEN
+from mi355fft import _abi
+from mi355fft.layout import createFftConvKernelMajorChannelLanePreset, resolve_plan_options
+
+
+def _desc(opts):
+    r = resolve_plan_options(opts)
+    return _abi.make_desc(r["type"], r["shape"], r["batch"], r["direction"], r["normalize"], r["inPlace"], r["input_layout"],
+                          r["output_layout"], r["conv"]), r
+
+
+def _close(got, want, atol, rtol, what):
+    from oracle import oracle as orc
+    orc.assert_close_elementwise(got, want, atol, rtol, what)
+
+
+@pytest.mark.parametrize("layout", ["kernel-major", "batch-major"])
+def test_fftconv_golden_fixtures(manifest, oracle, layout):
+    cases, _ = manifest
+    ran = 0
+    for c in cases.values():
+        if c["kind"] != "fftconv":
+            continue
+        shape, batch, K = c["shape"], c["batch"], c["kernelCount"]
+        ks = c["kernelShape"] or shape
+        fft_shape = shape if c["boundary"] == "circular" else [s + k - 1 for s, k in zip(shape, ks)]
+        if any(max(_factor_leftover(n), 1) != 1 for n in fft_shape):
+            continue  # FFT domain needs a prime factor > 13 (Bluestein route not built): covered by the error test below
+        n, kn = int(np.prod(shape)), int(np.prod(ks))
+        x = oracle.random_complex_interleaved(n * batch, c["seed"])
+        kern = oracle.random_complex_interleaved(kn * K, c["kernel_seed"])
+        want = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32).reshape(K, batch, -1)
+        desc, r = _desc({"type": "fftconv", "shape": shape, "batch": batch,
+                         "fftConv": {"mode": c["mode"], "boundary": c["boundary"], "kernelCount": K, "kernelShape": c["kernelShape"],
+                                     "outputLayout": layout}})
+        got, route, _ = emu.run_plan(desc, x, want.size, kernel=kern)
+        if layout == "batch-major":
+            want = want.transpose(1, 0, 2)
+        _close(got, want.reshape(-1), 4e-3, 4e-3, c["name"])   # the reference's own tolerance (complete.suite.js:4663)
+        assert oracle.rel_l2(got, want.reshape(-1)) < 1e-5, c["name"]
+        ran += 1
+    assert ran >= 7
+
+
+def _factor_leftover(n):
+    for r in (2, 3, 5, 7, 11, 13):
+        while n % r == 0:
+            n //= r
+    return n
+
+
+def test_fftconv_unsupported_domain_is_a_clean_error():
+    desc, _ = _desc({"type": "fftconv", "shape": [17], "batch": 1, "fftConv": {"boundary": "linear-full", "kernelShape": [7]}})  # 23 points
+    with pytest.raises(emu.EmuError) as e:
+        emu.run_plan(desc, np.zeros(34, np.float32), 2 * 23, kernel=np.zeros(14, np.float32))
+    assert e.value.code == _abi.ERR_UNSUPPORTED
+
+
+def _make_strided_physical(shape, batch, offset, batch_stride, logical, total_elems, fill=(0.0, 0.0)):
+    n = int(np.prod(shape))
+    phys = np.empty(2 * total_elems, np.float32)
+    phys[0::2], phys[1::2] = fill
+    for b in range(batch):
+        base = offset + b * batch_stride
+        phys[2 * base:2 * (base + n)] = logical[2 * b * n:2 * (b + 1) * n]
+    return phys
+
+
+def test_fftconv_channel_policy_lanes_preserve_sentinels(oracle):
+    """mirror of complete.suite.js:4715-4836 (N=12, batch=2, kernels=2, batch-major, lanes + sentinels)"""
+    shape, batch, K, n = [12], 2, 2, 12
+    in_ch, in_idx, in_cs, in_bs = 3, 1, 16, 80
+    out_ch, out_idx, out_cs, out_bs, step = 5, 1, 20, 160, 1
+    out_last = (out_idx + (K - 1) * step) * out_cs
+    out_elems = out_last + (batch - 1) * out_bs + n
+    logical = oracle.random_complex_interleaved(n * batch, 4242)
+    in_elems = in_idx * in_cs + (batch - 1) * in_bs + n
+    phys_in = _make_strided_physical(shape, batch, in_idx * in_cs, in_bs, logical, in_elems, fill=(9.0, 9.0))
+    kernels = oracle.random_complex_interleaved(n * K, 4343)
+    sentinel = np.empty(2 * out_elems, np.float32)
+    sentinel[0::2], sentinel[1::2] = 77.0, -55.0
+    desc, r = _desc({"type": "fftconv", "shape": shape, "batch": batch, "layout": {"interleavedComplex": True}, "precision": "f32",
+                     "fftConv": {"mode": "convolution", "kernelCount": K, "outputLayout": "batch-major",
+                                 "channelPolicy": {"input": {"channels": in_ch, "channelIndex": in_idx, "channelStrideElements": in_cs,
+                                                             "batchStrideElements": in_bs},
+                                                   "output": {"channels": out_ch, "channelIndex": out_idx, "channelStrideElements": out_cs,
+                                                              "batchStrideElements": out_bs, "kernelStepChannels": step}}}})
+    assert r["input_layout"] == {"strides": [1], "offset": in_idx * in_cs, "batch_stride": in_bs}
+    assert r["output_layout"] == {"strides": [1], "offset": out_idx * out_cs, "batch_stride": out_bs}
+    assert r["conv"]["outputKernelStrideElements"] == out_cs * step
+    got, _, _ = emu.run_plan(desc, phys_in, sentinel.size, kernel=kernels, out_init=sentinel)
+    want = sentinel.copy()
+    for k in range(K):
+        cpu, _ = oracle.fftconv_ref(logical, kernels[2 * k * n:2 * (k + 1) * n], shape, batch, "convolution")
+        for b in range(batch):
+            lane = (out_idx + k * step) * out_cs + b * out_bs
+            want[2 * lane:2 * (lane + n)] = cpu[2 * b * n:2 * (b + 1) * n]
+    _close(got, want, 5e-3, 5e-3, "channelPolicy lanes")
+    untouched = np.ones(out_elems, bool)
+    for k in range(K):
+        for b in range(batch):
+            lane = (out_idx + k * step) * out_cs + b * out_bs
+            untouched[lane:lane + n] = False
+    assert np.array_equal(got.reshape(-1, 2)[untouched], sentinel.reshape(-1, 2)[untouched]), "elements outside the lanes were written"
+
+
+def test_fftconv_cfg4_preset_against_golden(manifest, oracle):
+    """BASELINE config 4: shape=[256] batch=4, in=64ch out=128ch, 3 kernels, kernel-major channel-lane preset"""
+    cases, _ = manifest
+    c = cases["fftconv_cfg4_N256_b4_k3"]
+    preset = createFftConvKernelMajorChannelLanePreset({"shape": [256], "batch": 4, "kernelCount": 3, "input": {"channels": 64},
+                                                        "output": {"channels": 128, "kernelStepChannels": 16}})
+    opts = dict(preset, type="fftconv")
+    desc, r = _desc(opts)
+    n, batch, K = 256, 4, 3
+    logical = oracle.random_complex_interleaved(n * batch, c["seed"])
+    kern = oracle.random_complex_interleaved(n * K, c["kernel_seed"])
+    phys_in = _make_strided_physical([n], batch, 0, 64 * 256, logical, 4 * 64 * 256, fill=(5.0, -5.0))
+    out_elems = 4 * 128 * 256
+    sentinel = np.empty(2 * out_elems, np.float32)
+    sentinel[0::2], sentinel[1::2] = 77.0, -55.0
+    got, route, launches = emu.run_plan(desc, phys_in, sentinel.size, kernel=kern, out_init=sentinel)
+    gold = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32).reshape(K, batch, 2 * n)
+    want = sentinel.copy()
+    for k in range(K):
+        for b in range(batch):
+            lane = (0 + k * 16) * 256 + b * 32768
+            want[2 * lane:2 * (lane + n)] = gold[k, b]
+    _close(got, want, 4e-3, 4e-3, "cfg4 lanes")
+    lanes = np.zeros(out_elems, bool)
+    for k in range(K):
+        for b in range(batch):
+            lane = k * 16 * 256 + b * 32768
+            lanes[lane:lane + n] = True
+    assert oracle.rel_l2(got.reshape(-1, 2)[lanes], want.reshape(-1, 2)[lanes]) < 1e-5
+    assert np.array_equal(got.reshape(-1, 2)[~lanes], sentinel.reshape(-1, 2)[~lanes])

@@ -1,0 +1,383 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs; golden fixtures generated from the reference's math.js; size-independent properties at the
+BASELINE.json sizes.
+
+Tolerance (north_star: "within 1e-5 relative for f32"): norm-relative  ||a-e||2/||e||2 <= 1e-5 and
+max|a-e|/max|e| <= 1e-5 per case, plus the reference's own per-element form
+|a-e| <= atol + rtol*|e| at its own tolerances (3e-4 c2c, 8e-4 r2c, 2e-3 c2r, 4e-3..5e-3 fftconv:
+test/complete.suite.js:674,1797,1813,4663,4831)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fft():
+    import mi355fft
+    return mi355fft
+
+
+@pytest.fixture(scope="module")
+def dev(fft):
+    d = fft.Device(0)
+    yield d
+    d.close()
+
+
+def run_plan(fft, dev, opts, x, out_floats, kernel=None, out_init=None, in_place=False, use_graph=False):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    inp = fft.uploadComplex(dev, x)
+    out = None
+    if not in_place:
+        out = dev.createBuffer({"size": max(4 * out_floats, 8)})
+        if out_init is not None:
+            dev.queue.writeBuffer(out, 0, np.asarray(out_init, dtype=np.float32))
+    plan = fft.createPlan(dev, opts)
+    enc = dev.createCommandEncoder()
+    args = {"input": inp}
+    if out is not None:
+        args["output"] = out
+    if kernel is not None:
+        args["kernel"] = kernel
+    plan.exec(enc, args)
+    cb = enc.finish(use_graph=use_graph)
+    dev.queue.submit([cb])
+    dev.queue.onSubmittedWorkDone()
+    got = fft.downloadF32(dev, inp if in_place else out, out_floats)
+    route = plan.describe()
+    cb.release()
+    plan.destroy()
+    inp.destroy()
+    if out is not None:
+        out.destroy()
+    return got, route
+
+
+def check(oracle, got, want, what, atol=3e-4, rtol=3e-4, tol=TOL):
+    l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
+    assert l2 <= tol and mx <= tol, f"{what}: rel_l2={l2:.3e} rel_max={mx:.3e}"
+    oracle.assert_close_elementwise(got, want, atol, rtol, what)
+
+
+# ---- c2c ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096])
+def test_c2c_lines_all_sizes(fft, dev, oracle, n):
+    batch = 37 if n <= 1024 else 5       # ragged vs the tile size
+    x = oracle.random_complex_batch(n, batch, 0xA000 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward"), ("forward", "unitary")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert route.startswith("lines[") and launches == 1
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"c2c N={n} {direction} {norm}")
+
+
+def test_c2c_golden_fixture_cfg1(fft, dev, oracle, manifest):
+    """BASELINE config 1 (bench_1d_1024.js shape): N=1024 batch=1, against the reference's own output"""
+    cases, _ = manifest
+    c = cases["c2c_N1024_b1_forward_none"]
+    x = np.fromfile(os.path.join(GOLDEN, c["in_file"]), dtype=np.float32)
+    want = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32)
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [1024], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size)
+    check(oracle, got, want, "cfg1 golden")
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [1024], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size, use_graph=True)
+    check(oracle, got, want, "cfg1 golden via hipGraph")
+
+
+def test_c2c_in_place_and_offsets(fft, dev, oracle):
+    n, batch = 256, 6
+    x = oracle.random_complex_batch(n, batch, 77).reshape(-1)
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none", "inPlace": True}, x,
+                      x.size, in_place=True)
+    check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, "forward"), "in-place")
+    # inputOffsetBytes / outputOffsetBytes: transform the last 4 lines into the middle of a larger output
+    inp = fft.uploadComplex(dev, x)
+    out = dev.createBuffer({"size": x.nbytes * 2})
+    dev.queue.writeBuffer(out, 0, np.full(2 * x.size, 3.0, np.float32))
+    plan = fft.createPlan(dev, {"type": "c2c", "shape": [n], "batch": 4, "direction": "inverse", "normalize": "unitary"})
+    enc = dev.createCommandEncoder()
+    plan.exec(enc, {"input": inp, "output": out, "inputOffsetBytes": 2 * n * 8, "outputOffsetBytes": 1024})
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    full = fft.downloadF32(dev, out, 2 * x.size)
+    want = oracle.c2c_ref_batch(x[2 * n * 2:], [n], 4, "inverse", "unitary")
+    check(oracle, full[256:256 + want.size], want, "offsets")
+    assert np.all(full[:256] == 3.0) and np.all(full[256 + want.size:] == 3.0)
+    with pytest.raises(fft.Mi355Error, match="multiples of 8"):
+        plan.exec(dev.createCommandEncoder(), {"input": inp, "output": out, "inputOffsetBytes": 4})
+    with pytest.raises(fft.Mi355Error, match="too small"):
+        plan.exec(dev.createCommandEncoder(), {"input": inp, "output": out, "inputOffsetBytes": x.nbytes - 8})
+    plan.destroy()
+    with pytest.raises(fft.Mi355Error, match="plan destroyed"):
+        plan.exec(dev.createCommandEncoder(), {"input": inp, "output": out})
+    plan.destroy()  # idempotent
+    inp.destroy()
+    out.destroy()
+
+
+@pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21])
+def test_c2c_two_pass(fft, dev, oracle, lg):
+    n, batch = 1 << lg, 3 if lg <= 18 else 2
+    x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
+    for direction in ("forward", "inverse"):
+        got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
+        assert route.startswith("two-pass[")
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"two-pass 2^{lg} {direction}")
+
+
+def test_c2c_large_golden_samples(fft, dev, oracle, manifest):
+    """F3: N=2^20 single transform vs the reference's sampled bins + sum of squares"""
+    cases, _ = manifest
+    for name in ("c2c_N2p20_forward", "c2c_N2p20_inverse", "c2c_N2p16_forward", "c2c_N2p21_forward"):
+        c = cases[name]
+        n = c["shape"][0]
+        x = oracle.random_complex_interleaved(n, c["seed"])
+        got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": 1, "direction": c["direction"], "normalize": "none"}, x, x.size)
+        idx = np.asarray(c["sample_idx"])
+        want = np.asarray(c["sample_vals"], dtype=np.float32).reshape(-1, 2)
+        g = got.reshape(-1, 2)[idx]
+        scale = float(np.sqrt(c["out_sumsq"] / n))           # rms magnitude of an output bin
+        assert float(np.max(np.abs(g.astype(np.float64) - want))) <= 2e-5 * scale * 8, name
+        assert abs(float(np.sum(got.astype(np.float64) ** 2)) / c["out_sumsq"] - 1.0) < 1e-5, name
+
+
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 96, 105, 210, 1001, 1144, 3 * 4096])
+def test_c2c_mixed_radix(fft, dev, oracle, n):
+    batch = 4
+    x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
+        assert route.startswith("stages[")
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"generic N={n} {direction}", 3e-3, 3e-3)
+
+
+@pytest.mark.parametrize("shape", [[8, 4], [16, 16], [4, 8, 2], [96, 105], [24, 25, 27], [1024, 8], [64, 64, 4]])
+def test_c2c_nd(fft, dev, oracle, shape):
+    n, batch = int(np.prod(shape)), 2
+    x = oracle.random_complex_batch(n, batch, 0xD000 + n).reshape(-1)
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "unitary"}, x, x.size)
+    check(oracle, got, oracle.c2c_ref_batch(x, shape, batch, "forward", "unitary"), f"nd {shape}", 3e-3, 3e-3)
+
+
+def test_c2c_nd_golden(fft, dev, oracle, manifest):
+    cases, _ = manifest
+    for name in ("c2c_nd_8x4_forward", "c2c_nd_16x16_inverse", "c2c_nd_4x8x2_forward"):
+        c = cases[name]
+        n = int(np.prod(c["shape"]))
+        x = oracle.random_complex_interleaved(n, c["seed"])
+        got, _ = run_plan(fft, dev, {"type": "c2c", "shape": c["shape"], "batch": 1, "direction": c["direction"], "normalize": c["normalize"]}, x, x.size)
+        want = oracle.fftnd_ref(x, c["shape"], c["direction"], c["normalize"])
+        assert format(oracle.fnv1a64(want), "016x") == c["out_fnv1a64"]
+        check(oracle, got, want, name)
+
+
+def test_strided_layout_whdcn(fft, dev, oracle):
+    """layout.whdcn channel lanes on c2c: only the addressed lane is read / written"""
+    n, batch, channels, cidx = 64, 3, 4, 2
+    logical = oracle.random_complex_batch(n, batch, 0xF00).reshape(-1)
+    phys = np.full(2 * batch * channels * n, 9.0, np.float32)
+    for b in range(batch):
+        base = b * channels * n + cidx * n
+        phys[2 * base:2 * (base + n)] = logical[2 * b * n:2 * (b + 1) * n]
+    sentinel = np.full(phys.size, -4.0, np.float32)
+    opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none",
+            "layout": {"interleavedComplex": True, "whdcn": {"channels": channels, "channelIndex": cidx}}}
+    got, (route, _) = run_plan(fft, dev, opts, phys, phys.size, out_init=sentinel)
+    assert "gather" in route and "scatter" in route
+    want = sentinel.copy()
+    ref = oracle.c2c_ref_batch(logical, [n], batch, "forward")
+    for b in range(batch):
+        base = b * channels * n + cidx * n
+        want[2 * base:2 * (base + n)] = ref[2 * b * n:2 * (b + 1) * n]
+    check(oracle, got, want, "whdcn lanes")
+
+
+# ---- r2c / c2r ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 8192, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21])
+def test_r2c_c2r(fft, dev, oracle, n):
+    batch = 3 if n <= 4096 else 2
+    x = oracle.random_real_batch(n, batch, 0xE000 + n).reshape(-1)
+    p = n // 2 + 1
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    got, _ = run_plan(fft, dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}, x, 2 * p * batch)
+    check(oracle, got, want, f"r2c N={n}", 8e-4, 8e-4)
+    back, _ = run_plan(fft, dev, {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward"}, want, n * batch)
+    check(oracle, back, x, f"c2r(r2c) N={n}", 2e-3, 2e-3)
+
+
+def test_r2c_golden_fixtures(fft, dev, oracle, manifest):
+    cases, _ = manifest
+    seen = 0
+    for c in cases.values():
+        if c["kind"] == "r2c_dft" and c["N"] % 2 == 0:
+            x = oracle.random_real(c["N"], c["seed"])
+            want = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32)
+            got, _ = run_plan(fft, dev, {"type": "r2c", "shape": [c["N"]], "batch": 1, "direction": "forward", "normalize": c["normalize"]}, x, want.size)
+            check(oracle, got, want, c["name"], 8e-4, 8e-4)
+            seen += 1
+        elif c["kind"] == "c2r_dft" and c["N"] % 2 == 0:
+            xin = np.fromfile(os.path.join(GOLDEN, c["in_file"]), dtype=np.float32)
+            want = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32)
+            got, _ = run_plan(fft, dev, {"type": "c2r", "shape": [c["N"]], "batch": 1, "direction": "inverse", "normalize": c["normalize"]}, xin, want.size)
+            check(oracle, got, want, c["name"], 2e-3, 2e-3)
+            seen += 1
+        elif c["kind"] == "r2c_pow2" and c["N"] <= (1 << 22):
+            x = oracle.random_real(c["N"], c["seed"])
+            got, _ = run_plan(fft, dev, {"type": "r2c", "shape": [c["N"]], "batch": 1, "direction": "forward", "normalize": "none"}, x, c["N"] + 2)
+            idx = np.asarray(c["sample_idx"])
+            want = np.asarray(c["sample_vals"], dtype=np.float32).reshape(-1, 2)
+            scale = float(np.sqrt(np.mean(want.astype(np.float64) ** 2))) + 1e-30
+            assert float(np.max(np.abs(got.reshape(-1, 2)[idx].astype(np.float64) - want))) <= 2e-4 * scale, c["name"]
+            seen += 1
+    assert seen >= 20
+
+
+# ---- fftconv --------------------------------------------------------------------------------------------
+def test_fftconv_golden_fixtures(fft, dev, oracle, manifest):
+    cases, _ = manifest
+    ran = 0
+    for c in cases.values():
+        if c["kind"] != "fftconv":
+            continue
+        shape, batch, K = c["shape"], c["batch"], c["kernelCount"]
+        ks = c["kernelShape"] or shape
+        fshape = shape if c["boundary"] == "circular" else [s + k - 1 for s, k in zip(shape, ks)]
+        if any(_leftover(v) != 1 for v in fshape):
+            continue
+        n, kn = int(np.prod(shape)), int(np.prod(ks))
+        x = oracle.random_complex_interleaved(n * batch, c["seed"])
+        kern = oracle.random_complex_interleaved(kn * K, c["kernel_seed"])
+        want = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32)
+        opts = {"type": "fftconv", "shape": shape, "batch": batch,
+                "fftConv": {"mode": c["mode"], "boundary": c["boundary"], "kernelCount": K, "kernelShape": c["kernelShape"]}}
+        kernels = [kern[2 * k * kn:2 * (k + 1) * kn] for k in range(K)]      # array-of-kernels form
+        got, _ = run_plan(fft, dev, opts, x, want.size, kernel=kernels)
+        check(oracle, got, want, c["name"], 4e-3, 4e-3)
+        ran += 1
+    assert ran >= 7
+
+
+def _leftover(n):
+    for r in (2, 3, 5, 7, 11, 13):
+        while n % r == 0:
+            n //= r
+    return n
+
+
+def test_fftconv_cfg4_channel_lane_preset(fft, dev, oracle, manifest):
+    """BASELINE config 4 with sentinel preservation (mirror of complete.suite.js:4812-4830)"""
+    cases, _ = manifest
+    c = cases["fftconv_cfg4_N256_b4_k3"]
+    preset = fft.createFftConvKernelMajorChannelLanePreset({"shape": [256], "batch": 4, "kernelCount": 3, "input": {"channels": 64},
+                                                            "output": {"channels": 128, "kernelStepChannels": 16}})
+    n, batch, K = 256, 4, 3
+    logical = oracle.random_complex_interleaved(n * batch, c["seed"])
+    kern = oracle.random_complex_interleaved(n * K, c["kernel_seed"])
+    phys_in = np.full(2 * 4 * 64 * 256, 5.0, np.float32)
+    for b in range(batch):
+        phys_in[2 * b * 16384:2 * (b * 16384 + n)] = logical[2 * b * n:2 * (b + 1) * n]
+    out_elems = 4 * 128 * 256
+    sentinel = np.empty(2 * out_elems, np.float32)
+    sentinel[0::2], sentinel[1::2] = 77.0, -55.0
+    got, (route, launches) = run_plan(fft, dev, dict(preset, type="fftconv"), phys_in, sentinel.size, kernel=kern, out_init=sentinel)
+    gold = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32).reshape(K, batch, 2 * n)
+    want = sentinel.copy()
+    lanes = np.zeros(out_elems, bool)
+    for k in range(K):
+        for b in range(batch):
+            lane = k * 16 * 256 + b * 32768
+            want[2 * lane:2 * (lane + n)] = gold[k, b]
+            lanes[lane:lane + n] = True
+    oracle.assert_close_elementwise(got, want, 5e-3, 5e-3, "cfg4 lanes")
+    assert oracle.rel_l2(got.reshape(-1, 2)[lanes], want.reshape(-1, 2)[lanes]) < TOL
+    assert np.array_equal(got.reshape(-1, 2)[~lanes], sentinel.reshape(-1, 2)[~lanes])
+
+
+# ---- properties at the BASELINE sizes ---------------------------------------------------------------------
+def _full_size_properties(fft, dev, oracle, n, batch, seed):
+    """forward then inverse(backward) returns the input; Parseval; a sampled transform matches the oracle"""
+    info = dev.info()
+    bytes_needed = 3 * n * batch * 8
+    if info["hbm_free"] < bytes_needed + (2 << 30):
+        pytest.skip(f"needs {bytes_needed >> 30} GiB of HBM")
+    a = dev.createBuffer({"size": n * batch * 8})
+    b = dev.createBuffer({"size": n * batch * 8})
+    c = dev.createBuffer({"size": n * batch * 8})
+    dev.fillRandom(a, 0, 2 * n, batch, seed, 0)
+    fwd = fft.createPlan(dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
+    inv = fft.createPlan(dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward"})
+    enc = dev.createCommandEncoder()
+    fwd.exec(enc, {"input": a, "output": b})
+    inv.exec(enc, {"input": b, "output": c})          # two execs in one encoder run in order
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    e_in = dev.sumsq(a, 0, 2 * n * batch)
+    e_out = dev.sumsq(b, 0, 2 * n * batch)
+    assert abs(e_out / (n * e_in) - 1.0) < 1e-5, "Parseval"
+    rt = dev.diffSumsq(c, 0, a, 0, 1.0, 2 * n * batch)
+    assert np.sqrt(rt / e_in) < 1e-5, f"round trip rel_l2={np.sqrt(rt / e_in):.3e}"
+    # sampled transforms against the oracle (first, middle, last)
+    for t in (0, batch // 2, batch - 1):
+        x = oracle.random_complex_interleaved(n, oracle.stream_seed(seed, t))
+        dev_in = fft.downloadF32(dev, a, 2 * n, t * n * 8)
+        assert np.array_equal(dev_in, x), "device PRNG twin"
+        got = fft.downloadF32(dev, b, 2 * n, t * n * 8)
+        want = oracle.fft1d_ref(x, n, "forward")
+        l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
+        assert l2 <= TOL and mx <= TOL, f"transform {t}: rel_l2={l2:.3e} rel_max={mx:.3e}"
+    for p in (fwd, inv):
+        p.destroy()
+    for buf in (a, b, c):
+        buf.destroy()
+
+
+def test_cfg2_full_size_properties(fft, dev, oracle):
+    """BASELINE config 2: N=1024 batch=65536"""
+    _full_size_properties(fft, dev, oracle, 1024, 65536, 0x5EED0002)
+
+
+def test_cfg3_full_size_properties(fft, dev, oracle):
+    """BASELINE config 3 (north-star metric): N=2^20 batch=4096 — 32 GiB per buffer"""
+    _full_size_properties(fft, dev, oracle, 1 << 20, 4096, 0x5EED0003)
+
+
+def test_linearity_at_2p20(fft, dev, oracle):
+    n, batch = 1 << 20, 4
+    xs = [oracle.random_complex_batch(n, batch, 0x7100 + i).reshape(-1) for i in range(2)]
+    opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+    fa, _ = run_plan(fft, dev, opts, xs[0], xs[0].size)
+    fb, _ = run_plan(fft, dev, opts, xs[1], xs[1].size)
+    fs, _ = run_plan(fft, dev, opts, (2.0 * xs[0] - 0.5 * xs[1]).astype(np.float32), xs[0].size)
+    assert oracle.rel_l2(fs, 2.0 * fa.astype(np.float64) - 0.5 * fb.astype(np.float64)) < 1e-5
+
+
+def test_impulse_and_constant(fft, dev, oracle):
+    n = 1 << 20
+    x = np.zeros(2 * n, np.float32)
+    x[2 * 5] = 1.0                                    # delta at n=5 -> e^{-2 pi i 5k/N}
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size)
+    k = np.arange(n, dtype=np.float64)
+    want = np.exp(-2j * np.pi * 5 * k / n)
+    g = got.astype(np.float64).view(np.complex128)
+    assert np.max(np.abs(g - want)) < 2e-6
+    x = np.zeros(2 * n, np.float32)
+    x[0::2] = 1.0
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size)
+    assert abs(got[0] - n) < 1e-3 * n and np.max(np.abs(got[2:])) < 1e-2
+
+
+def test_torch_fft_cross_check(fft, dev, oracle):
+    """independent f32 FFT (torch.fft on the same GPU) agrees to f32 rounding — not the parity oracle"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    n, batch = 1 << 16, 4
+    x = oracle.random_complex_batch(n, batch, 0x7777).reshape(-1)
+    got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}, x, x.size)
+    t = torch.from_numpy(x.reshape(batch, n, 2).copy()).cuda()
+    ref = torch.view_as_real(torch.fft.fft(torch.view_as_complex(t), dim=1)).cpu().numpy().reshape(-1)
+    assert oracle.rel_l2(got, ref) < 2e-6

@@ -1,0 +1,460 @@
+// api.hip — the C ABI of libmi355fft.so (include/mi355fft.h): devices, buffers, plans, the recording
+// encoder and the queue.  Each entry point cites the reference interface it replaces in the header.
+//
+// Record vs execute: plan.exec only appends resolved launches to the encoder; finish()
+// freezes them into a command list — optionally a hipGraph captured from replaying the list on a capture
+// stream — and queue.submit enqueues it on the device stream.  There is no CPU fallback anywhere: with no
+// HIP device every call that needs one fails with MI355FFT_ERR_HIP and says so.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355fft.h"
+#include "hip_launcher.hpp"
+#include "plan.hpp"
+
+using namespace mi355;
+
+#define MI_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const char* fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+  do {                                                                                                      \
+    const hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return fail(MI355FFT_ERR_HIP, "HIP error %d (%s) in %s", (int)e_, hipGetErrorString(e_), #expr); \
+  } while (0)
+}  // namespace
+
+struct mi355fft_device {
+  int ordinal = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t capture_stream = nullptr;
+  int compute_units = 256;
+  std::string arch;
+};
+struct mi355fft_buffer {
+  mi355fft_device* dev = nullptr;
+  void* ptr = nullptr;
+  uint64_t bytes = 0;
+  bool owned = false;
+};
+struct RecordedOp { Step step; void* ptr[5]; };
+struct mi355fft_encoder {
+  mi355fft_device* dev = nullptr;
+  std::vector<RecordedOp> ops;
+};
+struct mi355fft_commands {
+  mi355fft_device* dev = nullptr;
+  std::vector<RecordedOp> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+struct mi355fft_plan {
+  mi355fft_device* dev = nullptr;
+  PlanIR ir;
+  void* table = nullptr;
+  void* arena = nullptr;
+  uint64_t arena_bytes = 0;
+  bool destroyed = false;
+};
+
+namespace {
+
+bool lines_dispatch(int family, int id, const LineArgs& a, unsigned grid, HipLauncher& l) {
+  switch (family) {
+    case FAM_ROW_SMALL: return launch_lines_family<FAM_ROW_SMALL>(id, a, grid, l);
+    case FAM_ROW_1K: return launch_lines_family<FAM_ROW_1K>(id, a, grid, l);
+    case FAM_ROW_BIG: return launch_lines_family<FAM_ROW_BIG>(id, a, grid, l);
+    case FAM_PASS_A: return launch_lines_family<FAM_PASS_A>(id, a, grid, l);
+    case FAM_PASS_B: return launch_lines_family<FAM_PASS_B>(id, a, grid, l);
+  }
+  return false;
+}
+
+int replay(const std::vector<RecordedOp>& ops, HipLauncher& l) {
+  for (const RecordedOp& op : ops) {
+    const bool ok = dispatch_step(op.step, op.ptr, l, [&](int fam, int id, const LineArgs& a, unsigned grid) { return lines_dispatch(fam, id, a, grid, l); });
+    if (!ok) return fail(MI355FFT_ERR_UNSUPPORTED, "no kernel instance for step kind %d variant %d", (int)op.step.kind, op.step.variant);
+    if (l.status != hipSuccess) return fail(MI355FFT_ERR_HIP, "HIP error %d (%s) launching step kind %d", (int)l.status, hipGetErrorString(l.status), (int)op.step.kind);
+  }
+  return MI355FFT_OK;
+}
+
+void destroy_commands(mi355fft_commands* c) {
+  if (c->exec) (void)hipGraphExecDestroy(c->exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  delete c;
+}
+
+}  // namespace
+
+MI_API int mi355fft_abi_version(void) { return MI355FFT_ABI_VERSION; }
+MI_API const char* mi355fft_last_error(void) { return g_err.c_str(); }
+
+// ---- device ----------------------------------------------------------------------------------------
+MI_API int mi355fft_device_count(int* count) {
+  if (!count) return fail(MI355FFT_ERR_INVALID, "count is NULL");
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(MI355FFT_ERR_HIP, "hipGetDeviceCount failed: %s (is this an MI355X box with /dev/kfd?)", hipGetErrorString(e)); }
+  *count = n;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_device_open(int ordinal, mi355fft_device** out) {
+  if (!out) return fail(MI355FFT_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  int n = 0;
+  int rc = mi355fft_device_count(&n);
+  if (rc) return rc;
+  if (n <= 0) return fail(MI355FFT_ERR_HIP, "Expected a HIP device: none visible (libmi355fft has no CPU path)");
+  if (ordinal < 0 || ordinal >= n) return fail(MI355FFT_ERR_INVALID, "device ordinal %d out of range [0,%d)", ordinal, n);
+  HIP_TRY(hipSetDevice(ordinal));
+  std::unique_ptr<mi355fft_device> d(new mi355fft_device());
+  d->ordinal = ordinal;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, ordinal));
+  d->compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  d->arch = prop.gcnArchName;
+  HIP_TRY(hipStreamCreate(&d->stream));
+  HIP_TRY(hipStreamCreateWithFlags(&d->capture_stream, hipStreamNonBlocking));
+  *out = d.release();
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_device_close(mi355fft_device* dev) {
+  if (!dev) return MI355FFT_OK;
+  (void)hipSetDevice(dev->ordinal);
+  (void)hipStreamSynchronize(dev->stream);
+  (void)hipStreamDestroy(dev->stream);
+  (void)hipStreamDestroy(dev->capture_stream);
+  delete dev;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_device_info(mi355fft_device* dev, uint64_t* hbm_total, uint64_t* hbm_free, int* compute_units, char arch[64]) {
+  if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  size_t fr = 0, tot = 0;
+  HIP_TRY(hipMemGetInfo(&fr, &tot));
+  if (hbm_total) *hbm_total = tot;
+  if (hbm_free) *hbm_free = fr;
+  if (compute_units) *compute_units = dev->compute_units;
+  if (arch) { std::snprintf(arch, 64, "%s", dev->arch.c_str()); }
+  return MI355FFT_OK;
+}
+
+MI_API void* mi355fft_device_stream(mi355fft_device* dev) { return dev ? (void*)dev->stream : nullptr; }
+
+// ---- buffers ---------------------------------------------------------------------------------------
+MI_API int mi355fft_buffer_alloc(mi355fft_device* dev, uint64_t bytes, mi355fft_buffer** out) {
+  if (!dev || !out) return fail(MI355FFT_ERR_INVALID, "Expected a device and an out pointer");
+  *out = nullptr;
+  if (bytes == 0) return fail(MI355FFT_ERR_INVALID, "createBuffer: size must be > 0");
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  void* p = nullptr;
+  const hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) return fail(MI355FFT_ERR_NOMEM, "hipMalloc(%llu bytes) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+  mi355fft_buffer* b = new mi355fft_buffer();
+  b->dev = dev; b->ptr = p; b->bytes = bytes; b->owned = true;
+  *out = b;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_buffer_wrap(mi355fft_device* dev, void* device_ptr, uint64_t bytes, mi355fft_buffer** out) {
+  if (!dev || !out || !device_ptr || bytes == 0) return fail(MI355FFT_ERR_INVALID, "buffer_wrap: device, pointer, size and out are required");
+  mi355fft_buffer* b = new mi355fft_buffer();
+  b->dev = dev; b->ptr = device_ptr; b->bytes = bytes; b->owned = false;
+  *out = b;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_buffer_free(mi355fft_buffer* buf) {
+  if (!buf) return MI355FFT_OK;
+  if (buf->owned && buf->ptr) {
+    (void)hipSetDevice(buf->dev->ordinal);
+    (void)hipStreamSynchronize(buf->dev->stream);   // submitted work may still use it
+    (void)hipFree(buf->ptr);
+  }
+  delete buf;
+  return MI355FFT_OK;
+}
+
+MI_API uint64_t mi355fft_buffer_size(const mi355fft_buffer* buf) { return buf ? buf->bytes : 0; }
+MI_API void* mi355fft_buffer_device_ptr(const mi355fft_buffer* buf) { return buf ? buf->ptr : nullptr; }
+
+MI_API int mi355fft_buffer_write(mi355fft_buffer* buf, uint64_t offset_bytes, const void* src, uint64_t bytes) {
+  if (!buf || (!src && bytes)) return fail(MI355FFT_ERR_INVALID, "writeBuffer: buffer and data are required");
+  if (offset_bytes + bytes > buf->bytes) return fail(MI355FFT_ERR_INVALID, "writeBuffer: range [%llu, %llu) exceeds buffer size %llu",
+                                                     (unsigned long long)offset_bytes, (unsigned long long)(offset_bytes + bytes), (unsigned long long)buf->bytes);
+  if (!bytes) return MI355FFT_OK;
+  HIP_TRY(hipSetDevice(buf->dev->ordinal));
+  HIP_TRY(hipMemcpyAsync((char*)buf->ptr + offset_bytes, src, bytes, hipMemcpyHostToDevice, buf->dev->stream));
+  HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_buffer_read(mi355fft_buffer* buf, uint64_t offset_bytes, void* dst, uint64_t bytes) {
+  if (!buf || (!dst && bytes)) return fail(MI355FFT_ERR_INVALID, "readback: buffer and destination are required");
+  if (offset_bytes + bytes > buf->bytes) return fail(MI355FFT_ERR_INVALID, "readback: range [%llu, %llu) exceeds buffer size %llu",
+                                                     (unsigned long long)offset_bytes, (unsigned long long)(offset_bytes + bytes), (unsigned long long)buf->bytes);
+  if (!bytes) return MI355FFT_OK;
+  HIP_TRY(hipSetDevice(buf->dev->ordinal));
+  HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+  HIP_TRY(hipMemcpy(dst, (const char*)buf->ptr + offset_bytes, bytes, hipMemcpyDeviceToHost));
+  return MI355FFT_OK;
+}
+
+// ---- plans -----------------------------------------------------------------------------------------
+MI_API int mi355fft_plan_create(mi355fft_device* dev, const mi355fft_plan_desc* desc, mi355fft_plan** out) {
+  if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
+  if (!desc || !out) return fail(MI355FFT_ERR_INVALID, "createPlan: options and out pointer are required");
+  *out = nullptr;
+  std::unique_ptr<mi355fft_plan> p(new mi355fft_plan());
+  p->dev = dev;
+  PlannerOptions opt = planner_options_from_env();
+  opt.compute_units = dev->compute_units;
+  std::string err;
+  const int rc = build_plan(*desc, opt, p->ir, err);
+  if (rc) return fail(rc, "%s", err.c_str());
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  const size_t tbytes = p->ir.table.size() * sizeof(float2h);
+  hipError_t e = hipMalloc(&p->table, tbytes);
+  if (e != hipSuccess) return fail(MI355FFT_ERR_NOMEM, "hipMalloc(twiddle tables, %zu bytes) failed: %s", tbytes, hipGetErrorString(e));
+  e = hipMemcpy(p->table, p->ir.table.data(), tbytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(p->table); return fail(MI355FFT_ERR_HIP, "uploading twiddle tables failed: %s", hipGetErrorString(e)); }
+  // raise dynamic-LDS limits now: hipFuncSetAttribute is not legal inside a later stream capture
+  {
+    HipLauncher l;
+    l.prepare_only = true;
+    std::vector<RecordedOp> probe;
+    for (const Step& s : p->ir.steps) if (s.kind == ST_LINES) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
+    const int prc = replay(probe, l);
+    if (prc) { (void)hipFree(p->table); return prc; }
+  }
+  *out = p.release();
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_plan_workspace_bytes(const mi355fft_plan* plan, uint64_t* bytes) {
+  if (!plan || !bytes) return fail(MI355FFT_ERR_INVALID, "plan and out pointer are required");
+  *bytes = plan->ir.work_bytes;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_plan_describe(const mi355fft_plan* plan, char* text, size_t text_bytes, int* launches_per_exec) {
+  if (!plan) return fail(MI355FFT_ERR_INVALID, "plan is required");
+  if (text && text_bytes) std::snprintf(text, text_bytes, "%s", plan->ir.route.c_str());
+  if (launches_per_exec) *launches_per_exec = (int)plan->ir.steps.size();
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_plan_exec(mi355fft_plan* plan, mi355fft_encoder* enc, const mi355fft_exec_args* args) {
+  if (!plan) return fail(MI355FFT_ERR_INVALID, "plan is required");
+  if (plan->destroyed) return fail(MI355FFT_ERR_DESTROYED, "plan destroyed");
+  if (!enc) return fail(MI355FFT_ERR_INVALID, "exec requires a command encoder");
+  if (!args || args->struct_size != sizeof(mi355fft_exec_args)) return fail(MI355FFT_ERR_INVALID, "exec options missing or ABI size mismatch");
+  if (enc->dev != plan->dev) return fail(MI355FFT_ERR_INVALID, "encoder and plan belong to different devices");
+  const mi355fft_plan_desc& d = plan->ir.desc;
+  if (!args->input) return fail(MI355FFT_ERR_INVALID, "exec requires input");
+  if (!d.in_place && !args->output) return fail(MI355FFT_ERR_INVALID, "exec requires output when inPlace=false");
+  if (d.in_place && args->output && (args->output != args->input || args->output_offset_bytes != args->input_offset_bytes))
+    return fail(MI355FFT_ERR_INVALID, "inPlace=true requires output omitted or equal to input");
+  if (args->input_offset_bytes % 8 || args->output_offset_bytes % 8 || args->kernel_offset_bytes % 8)
+    return fail(MI355FFT_ERR_INVALID, "inputOffsetBytes/outputOffsetBytes must be multiples of 8");
+  if (d.type == MI355FFT_FFTCONV && !args->kernel) return fail(MI355FFT_ERR_INVALID, "fftconv exec requires kernel");
+  mi355fft_buffer* out = d.in_place ? args->input : args->output;
+  const uint64_t out_off = d.in_place ? args->input_offset_bytes : args->output_offset_bytes;
+  if (!d.in_place && d.type != MI355FFT_C2C && args->output->ptr == args->input->ptr)
+    return fail(MI355FFT_ERR_INVALID, "input and output must be different buffers for this plan type");
+  if (args->input_offset_bytes + plan->ir.in_bytes > args->input->bytes)
+    return fail(MI355FFT_ERR_INVALID, "input buffer/view too small: need %llu bytes at offset %llu, have %llu", (unsigned long long)plan->ir.in_bytes,
+                (unsigned long long)args->input_offset_bytes, (unsigned long long)args->input->bytes);
+  if (out_off + plan->ir.out_bytes > out->bytes)
+    return fail(MI355FFT_ERR_INVALID, "output buffer/view too small: need %llu bytes at offset %llu, have %llu", (unsigned long long)plan->ir.out_bytes,
+                (unsigned long long)out_off, (unsigned long long)out->bytes);
+  if (d.type == MI355FFT_FFTCONV && args->kernel_offset_bytes + plan->ir.kernel_bytes > args->kernel->bytes)
+    return fail(MI355FFT_ERR_INVALID, "kernel buffer too small: need %llu bytes, have %llu", (unsigned long long)plan->ir.kernel_bytes,
+                (unsigned long long)args->kernel->bytes);
+  // workspace: caller's temp when it is big enough and does not alias input/output, else the plan's arena
+  void* work = nullptr;
+  if (plan->ir.work_bytes) {
+    if (args->temp && args->temp->bytes >= plan->ir.work_bytes && args->temp->ptr != args->input->ptr && args->temp->ptr != out->ptr) {
+      work = args->temp->ptr;
+    } else {
+      if (!plan->arena) {
+        HIP_TRY(hipSetDevice(plan->dev->ordinal));
+        const hipError_t e = hipMalloc(&plan->arena, plan->ir.work_bytes);
+        if (e != hipSuccess) return fail(MI355FFT_ERR_NOMEM, "hipMalloc(workspace, %llu bytes) failed: %s", (unsigned long long)plan->ir.work_bytes, hipGetErrorString(e));
+        plan->arena_bytes = plan->ir.work_bytes;
+      }
+      work = plan->arena;
+    }
+  }
+  char* base[5];
+  base[BUF_INPUT] = (char*)args->input->ptr + args->input_offset_bytes;
+  base[BUF_OUTPUT] = (char*)out->ptr + out_off;
+  base[BUF_WORK] = (char*)work;
+  base[BUF_KERNEL] = args->kernel ? (char*)args->kernel->ptr + args->kernel_offset_bytes : nullptr;
+  base[BUF_TABLE] = (char*)plan->table;
+  for (const Step& s : plan->ir.steps) {
+    RecordedOp op;
+    op.step = s;
+    for (int i = 0; i < 5; ++i) op.ptr[i] = s.p[i].buf == BUF_NONE ? nullptr : base[s.p[i].buf] + s.p[i].off;
+    enc->ops.push_back(op);
+  }
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_plan_destroy(mi355fft_plan* plan) {
+  if (!plan || plan->destroyed) return MI355FFT_OK;
+  (void)hipSetDevice(plan->dev->ordinal);
+  (void)hipStreamSynchronize(plan->dev->stream);
+  if (plan->table) (void)hipFree(plan->table);
+  if (plan->arena) (void)hipFree(plan->arena);
+  plan->table = plan->arena = nullptr;
+  plan->destroyed = true;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_plan_release(mi355fft_plan* plan) {
+  if (!plan) return MI355FFT_OK;
+  mi355fft_plan_destroy(plan);
+  delete plan;
+  return MI355FFT_OK;
+}
+
+// ---- encoder / queue -------------------------------------------------------------------------------
+MI_API int mi355fft_encoder_begin(mi355fft_device* dev, mi355fft_encoder** out) {
+  if (!dev || !out) return fail(MI355FFT_ERR_INVALID, "Expected a device and an out pointer");
+  mi355fft_encoder* e = new mi355fft_encoder();
+  e->dev = dev;
+  *out = e;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_encoder_copy_buffer(mi355fft_encoder* enc, mi355fft_buffer* src, uint64_t src_offset, mi355fft_buffer* dst,
+                                        uint64_t dst_offset, uint64_t bytes) {
+  if (!enc || !src || !dst) return fail(MI355FFT_ERR_INVALID, "copyBufferToBuffer: encoder, source and destination are required");
+  if (src_offset + bytes > src->bytes || dst_offset + bytes > dst->bytes) return fail(MI355FFT_ERR_INVALID, "copyBufferToBuffer: range exceeds buffer size");
+  if (bytes % 4 || src_offset % 4 || dst_offset % 4) return fail(MI355FFT_ERR_INVALID, "copyBufferToBuffer: offsets and size must be multiples of 4");
+  RecordedOp op;
+  op.step.kind = ST_COPY;
+  op.step.i[0] = (int64_t)bytes;
+  std::memset(op.ptr, 0, sizeof op.ptr);
+  op.ptr[0] = (char*)src->ptr + src_offset;
+  op.ptr[1] = (char*)dst->ptr + dst_offset;
+  enc->ops.push_back(op);
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_encoder_discard(mi355fft_encoder* enc) { delete enc; return MI355FFT_OK; }
+
+MI_API int mi355fft_encoder_finish(mi355fft_encoder* enc, int use_graph, mi355fft_commands** out) {
+  if (!enc || !out) return fail(MI355FFT_ERR_INVALID, "finish: encoder and out pointer are required");
+  *out = nullptr;
+  std::unique_ptr<mi355fft_encoder> owner(enc);
+  mi355fft_commands* c = new mi355fft_commands();
+  c->dev = enc->dev;
+  c->ops.swap(enc->ops);
+  if (use_graph && !c->ops.empty()) {
+    mi355fft_device* dev = c->dev;
+    hipError_t e = hipSetDevice(dev->ordinal);
+    if (e == hipSuccess) e = hipStreamBeginCapture(dev->capture_stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) { destroy_commands(c); return fail(MI355FFT_ERR_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e)); }
+    HipLauncher l;
+    l.stream = dev->capture_stream;
+    const int rc = replay(c->ops, l);
+    e = hipStreamEndCapture(dev->capture_stream, &c->graph);
+    if (rc) { destroy_commands(c); return rc; }
+    if (e != hipSuccess) { destroy_commands(c); return fail(MI355FFT_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e)); }
+    e = hipGraphInstantiate(&c->exec, c->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) { destroy_commands(c); return fail(MI355FFT_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e)); }
+  }
+  *out = c;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_queue_submit(mi355fft_device* dev, mi355fft_commands* cmds) {
+  if (!dev || !cmds) return fail(MI355FFT_ERR_INVALID, "submit: device and command list are required");
+  if (cmds->dev != dev) return fail(MI355FFT_ERR_INVALID, "command list belongs to a different device");
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  if (cmds->exec) { HIP_TRY(hipGraphLaunch(cmds->exec, dev->stream)); return MI355FFT_OK; }
+  HipLauncher l;
+  l.stream = dev->stream;
+  return replay(cmds->ops, l);
+}
+
+MI_API int mi355fft_commands_release(mi355fft_commands* cmds) {
+  if (!cmds) return MI355FFT_OK;
+  (void)hipSetDevice(cmds->dev->ordinal);
+  (void)hipStreamSynchronize(cmds->dev->stream);
+  destroy_commands(cmds);
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_queue_wait(mi355fft_device* dev) {
+  if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  return MI355FFT_OK;
+}
+
+// ---- synthetic inputs / reductions -----------------------------------------------------------------
+MI_API int mi355fft_fill_random(mi355fft_device* dev, mi355fft_buffer* buf, uint64_t offset_bytes, uint64_t row_floats, uint64_t rows,
+                                uint32_t seed0, uint64_t first_transform) {
+  if (!dev || !buf) return fail(MI355FFT_ERR_INVALID, "fill_random: device and buffer are required");
+  if (offset_bytes % 4 || offset_bytes + row_floats * rows * 4 > buf->bytes) return fail(MI355FFT_ERR_INVALID, "fill_random: range exceeds buffer");
+  if (!row_floats || !rows) return MI355FFT_OK;
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  const uint64_t total = row_floats * rows;
+  const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, (uint64_t)dev->compute_units * 16);
+  hipLaunchKernelGGL(fill_random_kernel, dim3(grid), dim3(256), 0, dev->stream, (float*)((char*)buf->ptr + offset_bytes),
+                     (unsigned long long)row_floats, (unsigned long long)rows, (unsigned)seed0, (unsigned long long)first_transform);
+  HIP_TRY(hipGetLastError());
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_diff_sumsq(mi355fft_device* dev, mi355fft_buffer* a, uint64_t a_offset_bytes, mi355fft_buffer* b, uint64_t b_offset_bytes,
+                               double alpha, uint64_t count, double* out) {
+  if (!dev || !a || !out) return fail(MI355FFT_ERR_INVALID, "sumsq: device, buffer and out are required");
+  if (a_offset_bytes % 4 || a_offset_bytes + count * 4 > a->bytes) return fail(MI355FFT_ERR_INVALID, "sumsq: range exceeds buffer a");
+  if (b && (b_offset_bytes % 4 || b_offset_bytes + count * 4 > b->bytes)) return fail(MI355FFT_ERR_INVALID, "sumsq: range exceeds buffer b");
+  *out = 0.0;
+  if (!count) return MI355FFT_OK;
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  const unsigned grid = (unsigned)std::min<uint64_t>((count + 255) / 256, (uint64_t)dev->compute_units * 8);
+  double* partial = nullptr;
+  HIP_TRY(hipMalloc((void**)&partial, grid * sizeof(double)));
+  hipLaunchKernelGGL(diff_sumsq_kernel, dim3(grid), dim3(256), 0, dev->stream, (const float*)((const char*)a->ptr + a_offset_bytes),
+                     b ? (const float*)((const char*)b->ptr + b_offset_bytes) : (const float*)nullptr, alpha, (unsigned long long)count, partial);
+  hipError_t e = hipGetLastError();
+  std::vector<double> host(grid);
+  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
+  if (e == hipSuccess) e = hipMemcpy(host.data(), partial, grid * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(partial);
+  if (e != hipSuccess) return fail(MI355FFT_ERR_HIP, "sumsq failed: %s", hipGetErrorString(e));
+  double s = 0.0;
+  for (double v : host) s += v;
+  *out = s;
+  return MI355FFT_OK;
+}
+
+MI_API int mi355fft_sumsq(mi355fft_device* dev, mi355fft_buffer* buf, uint64_t offset_bytes, uint64_t count, double* out) {
+  return mi355fft_diff_sumsq(dev, buf, offset_bytes, nullptr, 0, 0.0, count, out);
+}

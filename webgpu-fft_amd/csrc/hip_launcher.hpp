@@ -1,0 +1,51 @@
+// hip_launcher.hpp — the product Launcher for dispatch.hpp: enqueues kernels on a HIP stream (the device
+// queue, or a capturing stream while a command list is being turned into a hipGraph).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <unordered_set>
+
+#include "dispatch.hpp"
+
+namespace mi355 {
+
+struct HipLauncher {
+  hipStream_t stream = nullptr;
+  bool prepare_only = false;   // only raise dynamic-LDS limits (must happen outside stream capture)
+  hipError_t status = hipSuccess;
+
+  static void raise_lds_limit(const void* fn, unsigned smem, hipError_t& status) {
+    static std::mutex mu;
+    static std::unordered_set<const void*> done;
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count(fn)) return;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { status = e; return; }
+    done.insert(fn);
+  }
+
+  template <class... P, class... A>
+  void launch(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args) {
+    if (status != hipSuccess) return;
+    if (smem > 48 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kernel), smem, status);
+    if (prepare_only || status != hipSuccess) return;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), smem, stream, static_cast<P>(args)...);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) status = e;
+  }
+  void copy(void* dst, const void* src, size_t bytes) {
+    if (prepare_only || status != hipSuccess) return;
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) status = e;
+  }
+};
+
+// per-family instantiations live in lines_fam*.hip so that device code compiles in parallel
+extern template bool launch_lines_family<FAM_ROW_SMALL, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+extern template bool launch_lines_family<FAM_ROW_1K, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+extern template bool launch_lines_family<FAM_ROW_BIG, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+extern template bool launch_lines_family<FAM_PASS_A, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+extern template bool launch_lines_family<FAM_PASS_B, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+
+}  // namespace mi355

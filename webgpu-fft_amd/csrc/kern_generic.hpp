@@ -36,7 +36,7 @@ struct StageArgs {
 };
 
 template <int R>
-__global__ void __launch_bounds__(256) stockham_stage_kernel(const StageArgs a) {
+static __global__ void __launch_bounds__(256) stockham_stage_kernel(const StageArgs a) {
   const long long nb = a.N / R;  // butterflies per line
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
     // consecutive threads walk the contiguous direction: inner index fastest when S > 1
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) stockham_stage_kernel(const StageArgs a) 
 }
 
 // data[i] *= s  (float granularity so the same kernel serves real and complex buffers)
-__global__ void __launch_bounds__(256) scale_kernel(float* data, long long count, float s) {
+static __global__ void __launch_bounds__(256) scale_kernel(float* data, long long count, float s) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
     data[i] *= s;
 }
@@ -80,7 +80,7 @@ struct R2cPostArgs {
   long long x_line_stride;  // elements between packed lines (H+1 when dense)
   float scale;
 };
-__global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
+static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
   const long long per = a.H + 1;
   const long long total = a.batch * per;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
@@ -106,7 +106,7 @@ struct C2rPreArgs {
   long long H, batch;
   long long x_line_stride;
 };
-__global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
+static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
   const long long total = a.batch * a.H;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / a.H, k = g - b * a.H;
@@ -122,25 +122,25 @@ __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
 }
 
 // odd-N real paths: expand real -> complex (imag 0) and take the real part
-__global__ void __launch_bounds__(256) real_to_complex_kernel(const float* x, cf* z, long long count) {
+static __global__ void __launch_bounds__(256) real_to_complex_kernel(const float* x, cf* z, long long count) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
     cf v = {x[i], 0.0f};
     z[i] = v;
   }
 }
-__global__ void __launch_bounds__(256) complex_to_real_kernel(const cf* z, float* x, long long count, float s) {
+static __global__ void __launch_bounds__(256) complex_to_real_kernel(const cf* z, float* x, long long count, float s) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
     x[i] = z[i].x * s;
 }
 // full complex line (N) -> first N/2+1 bins, and the Hermitian expansion back (odd N route)
-__global__ void __launch_bounds__(256) pack_half_kernel(const cf* full, cf* packed, long long N, long long P, long long batch, long long packed_stride, float s) {
+static __global__ void __launch_bounds__(256) pack_half_kernel(const cf* full, cf* packed, long long N, long long P, long long batch, long long packed_stride, float s) {
   const long long total = batch * P;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / P, k = g - b * P;
     packed[b * packed_stride + k] = full[b * N + k] * s;
   }
 }
-__global__ void __launch_bounds__(256) unpack_hermitian_kernel(const cf* packed, cf* full, long long N, long long P, long long batch, long long packed_stride) {
+static __global__ void __launch_bounds__(256) unpack_hermitian_kernel(const cf* packed, cf* full, long long N, long long P, long long batch, long long packed_stride) {
   const long long total = batch * N;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / N, k = g - b * N;
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) unpack_hermitian_kernel(const cf* packed,
 }
 
 // data[b][i] *= (conj?) kern[i]   — frequency-domain product of fftconv (fft_conv.js:3-31)
-__global__ void __launch_bounds__(256) pointwise_mul_kernel(const cf* data, cf* out, const cf* kern, long long L, long long total, int conj_kernel, float s) {
+static __global__ void __launch_bounds__(256) pointwise_mul_kernel(const cf* data, cf* out, const cf* kern, long long L, long long total, int conj_kernel, float s) {
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const cf k = kern[g % L];
     const cf d = data[g];
@@ -176,7 +176,7 @@ struct StridedArgs {
   long long dense_offset, dense_batch_stride;
 };
 template <bool GATHER>
-__global__ void __launch_bounds__(256) strided_copy_kernel(const StridedArgs a) {
+static __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedArgs a) {
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / a.per;
     long long rem = g - b * a.per;
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedArgs a) 
   }
 }
 
-__global__ void __launch_bounds__(256) zero_kernel(float* data, long long count) {
+static __global__ void __launch_bounds__(256) zero_kernel(float* data, long long count) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) data[i] = 0.0f;
 }
 
@@ -208,7 +208,7 @@ MI_DEV unsigned stream_seed(unsigned seed0, unsigned long long b) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
-__global__ void __launch_bounds__(256) fill_random_kernel(float* out, unsigned long long row_floats, unsigned long long rows, unsigned seed0,
+static __global__ void __launch_bounds__(256) fill_random_kernel(float* out, unsigned long long row_floats, unsigned long long rows, unsigned seed0,
                                                          unsigned long long first_transform) {
   const unsigned long long total = row_floats * rows;
   for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (unsigned long long)gridDim.x * blockDim.x) {
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) fill_random_kernel(float* out, unsigned l
 }
 
 // partial[block] = sum over the block's grid-stride slice of (a[i] - alpha*b[i])^2 in f64 (b may be null)
-__global__ void __launch_bounds__(256) diff_sumsq_kernel(const float* a, const float* b, double alpha, unsigned long long count, double* partial) {
+static __global__ void __launch_bounds__(256) diff_sumsq_kernel(const float* a, const float* b, double alpha, unsigned long long count, double* partial) {
   double acc = 0.0;
   for (unsigned long long g = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; g < count; g += (unsigned long long)gridDim.x * blockDim.x) {
     const double d = (double)a[g] - (b ? alpha * (double)b[g] : 0.0);
