@@ -68,7 +68,7 @@ struct PlanIR {
 };
 
 struct PlannerOptions {
-  uint64_t chunk_bytes = 64ull << 20;  // two-pass: bytes of inter-pass intermediate kept hot in Infinity Cache
+  uint64_t chunk_bytes = 1ull << 30;   // two-pass: bytes of inter-pass intermediate per launch pair (measured: larger is faster)
   int compute_units = 256;
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
 };
