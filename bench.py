@@ -112,19 +112,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch  # first: its bundled HIP runtime is the one the library then binds to
-    import torch.distributed as dist
-    use_dist = world > 1
-    if use_dist:
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
     import mi355fft
+    from mi355fft.sharding import Group, rank_info, shard_range
+    rank, local_rank, world = rank_info()
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+    group = Group("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; barrier + scalar reductions only
+
     typ, n, batch, bytes_per_point, desc = WORKLOADS[args.workload]
     dev = mi355fft.Device(local_rank, use_graph=not args.no_graph)
     info = dev.info()
@@ -142,8 +137,10 @@ def main():
 
     inp = dev.createBuffer({"size": in_bytes})
     out = dev.createBuffer({"size": out_bytes})
-    # synthetic input, generated on the device: transform b of rank r is stream (seed0, r*batch + b)
-    dev.fillRandom(inp, 0, in_row_floats, batch, 0x5EED0003, rank * batch)
+    # synthetic input, generated on the device: this rank's shard [first, first+batch) of the global batch
+    first, last = shard_range(rank, world, batch * world)
+    assert last - first == batch
+    dev.fillRandom(inp, 0, in_row_floats, batch, 0x5EED0003, first)
     plan = mi355fft.createPlan(dev, opts)
     route, launches = plan.describe()
     enc = dev.createCommandEncoder()
@@ -155,8 +152,7 @@ def main():
     def barrier():
         dev.queue.onSubmittedWorkDone()
         torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        group.barrier()
 
     for _ in range(args.warmup):
         dev.queue.submit([cmds])
@@ -173,10 +169,7 @@ def main():
     barrier()
 
     # MAX over ranks of the wall time around the K steps (and of the device-event time)
-    times = torch.tensor([wall, dev_ms / 1e3], dtype=torch.float64, device=f"cuda:{local_rank}")
-    if use_dist:
-        dist.all_reduce(times, op=dist.ReduceOp.MAX)
-    wall_max, dev_max = float(times[0]), float(times[1])
+    wall_max, dev_max = group.reduce_max([wall, dev_ms / 1e3])
 
     if rank == 0:
         points_per_step = float(n) * batch * world
@@ -212,8 +205,7 @@ def main():
     inp.destroy()
     out.destroy()
     dev.close()
-    if use_dist:
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == "__main__":

@@ -51,6 +51,19 @@ def test_c2c_two_pass(oracle, lg, direction):
     check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"two-pass 2^{lg} {direction}")
 
 
+@pytest.mark.parametrize("lg,grid", [(13, 4), (14, 8), (15, 8)])
+def test_c2c_two_pass_hoisted_fourstep_roots(oracle, lg, grid, monkeypatch):
+    """grid*T a multiple of N1: pass B computes its four-step roots once per launch (loop-invariant registers)"""
+    monkeypatch.setenv("MI355_EMU_MAX_GRID", str(grid))
+    n, batch = 1 << lg, 5
+    x = oracle.random_complex_batch(n, batch, 0xB100 + lg).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc = _abi.make_desc("c2c", [n], batch, direction, "none")
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert route.startswith("two-pass[")
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"hoisted 2^{lg} {direction}")
+
+
 @pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 24, 96, 105, 210, 1001, 8 * 13 * 11])
 def test_c2c_generic_mixed_radix(oracle, n):
     batch = 2

@@ -110,7 +110,10 @@ int main(int argc, char** argv) {
   // pass B: ROW in (row stride 1024), COL out S = 1024
   a.tw = t3232;
   a.in_S = 1; a.in_outer_stride = 1024; a.out_S = 1024; a.out_outer_stride = N;
-  run_lines<LineCfg<1024, 32, 32, 1, 16, false, true, false, false, 0>>("passB 32x32 T16", tm, a, B * 64, 256, rw);
+  a.fs_group = 1024;
+  run_lines<LineCfg<1024, 32, 32, 1, 16, false, true, false, false, 0>>("passB 32x32 T16 NO twid", tm, a, B * 64, 256, rw);
+  run_lines<LineCfg<1024, 32, 32, 1, 16, false, true, false, false, 2>>("passB 32x32 T16 twid-in hoisted", tm, a, B * 64, 256, rw);
+  run_lines<LineCfg<1024, 32, 32, 1, 16, false, true, false, false, 2>>("passB 32x32 T16 twid-in per-tile (grid 250)", tm, a, B * 64, 250, rw);
   a.tw = t16164;
   run_lines<LineCfg<1024, 16, 16, 4, 16, false, true, false, false, 0>>("passB 16x16x4 T16 (1024 thr)", tm, a, B * 64, 256, rw);
   // ROW/ROW

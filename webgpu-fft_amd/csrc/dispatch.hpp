@@ -34,11 +34,11 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
   MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, false, false, 0) \
   MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, true, true, 0)
 #define LINE_PASS_A(N, R0, R1, R2, T)                               \
-  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 1) \
-  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 1)
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 0) \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 0)
 #define LINE_PASS_B(N, R0, R1, R2, T)                                \
-  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, false, 0) \
-  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, true, 0)
+  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, false, 2) \
+  MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, true, 2)
 #include "line_kernels.def"
 #undef LINE_ROW
 #undef LINE_PASS_A
@@ -74,7 +74,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) 
       a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2]; a.tw_lo = (const cf*)ptr[3]; a.tw_hi = (const cf*)ptr[4];
       a.num_tiles = s.i[0]; a.num_lines = s.i[1];
       a.in_S = s.i[2]; a.in_outer_stride = s.i[3]; a.out_S = s.i[4]; a.out_outer_stride = s.i[5];
-      a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7];
+      a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7]; a.fs_group = s.i[8] ? s.i[8] : 1;
       a.scale = s.f[0];
       const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
       return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);

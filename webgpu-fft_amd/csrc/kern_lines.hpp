@@ -30,7 +30,12 @@
 
 namespace mi355 {
 
-enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1 };
+// four-step twiddle e^{-2 pi i (line index in its group) * (element index) / Ntot}:
+//   TWID_FOURSTEP_OUT  multiplied into the last stage's outputs (LO table staged in LDS, HI from global)
+//   TWID_FOURSTEP_IN   multiplied into the first stage's inputs from per-thread registers that are computed
+//                      once per kernel launch when every tile of a workgroup has the same position inside its
+//                      group (grid * T is a multiple of the group), else once per tile
+enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1, TWID_FOURSTEP_IN = 2 };
 
 struct LineArgs {
   const cf* in;
@@ -47,6 +52,7 @@ struct LineArgs {
   float scale;
   int fs_shift;
   unsigned fs_lo_mask;
+  long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group)
 };
 
 template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_, bool SWAP_IN_, bool SWAP_OUT_, int TWID_>
@@ -114,6 +120,23 @@ template <class C, int S> MI_DEV void thread_map(int t, int& line, int& u) {
 template <bool COL> MI_DEV long long tile_base(long long G0, long long S, long long outer_stride) {
   if constexpr (COL) { const long long o = G0 / S; return o * outer_stride + (G0 - o * S); }
   else return G0 * outer_stride;
+}
+
+// per-thread four-step roots for the first stage's inputs (TWID_FOURSTEP_IN)
+template <class C>
+MI_DEV void fourstep_in_roots(cf (&fsw)[C::E], const LineArgs& a, long long tile, int t) {
+  using I = StageInfo<C, 0>;
+  int line, u; thread_map<C, 0>(t, line, u);
+  const unsigned gi = (unsigned)((tile * C::T + line) % a.fs_group);
+#pragma unroll
+  for (int b = 0; b < I::NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < I::R; ++q) {
+      const unsigned idx = (unsigned)(u + b * C::TPL + q * (C::N / I::R));
+      const unsigned m = gi * idx;
+      fsw[b * I::R + q] = cmul(a.tw_hi[m >> a.fs_shift], a.tw_lo[m & a.fs_lo_mask]);
+    }
+  }
 }
 
 template <class C, int S>
@@ -216,9 +239,20 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
   }
   if constexpr (C::TW_ELEMS > 0 || C::LO_ELEMS > 0) __syncthreads();
 
+  cf fsw[C::TWID == TWID_FOURSTEP_IN ? C::E : 1];
+  // every tile of this workgroup sits at the same position inside its group <=> the tile stride is a
+  // multiple of the group: the roots are then loop-invariant and computed once per launch
+  const bool fs_hoist = C::TWID == TWID_FOURSTEP_IN && ((long long)gridDim.x * C::T) % a.fs_group == 0;
+  if constexpr (C::TWID == TWID_FOURSTEP_IN) { if (fs_hoist) fourstep_in_roots<C>(fsw, a, blockIdx.x, t); }
+
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
     stage_read<C, 0>(v, a, tile, t, lds);
+    if constexpr (C::TWID == TWID_FOURSTEP_IN) {
+      if (!fs_hoist) fourstep_in_roots<C>(fsw, a, tile, t);
+#pragma unroll
+      for (int e = 0; e < C::E; ++e) v[e] = cmul(v[e], fsw[e]);
+    }
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, lo_lds);
     if constexpr (C::NSTAGES >= 2) {
       lines_sync<C>();

@@ -45,11 +45,11 @@ const std::vector<LineKernelMeta>& line_kernel_registry() {
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, false, false, 0)); \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, true, true, 0));
 #define LINE_PASS_A(N, R0, R1, R2, T)                                        \
-  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 1)); \
-  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 1));
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 0)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 0));
 #define LINE_PASS_B(N, R0, R1, R2, T)                                         \
-  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, false, 0)); \
-  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, true, 0));
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, false, 2)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, true, 2));
 #include "line_kernels.def"
 #undef LINE_ROW
 #undef LINE_PASS_A
@@ -183,8 +183,8 @@ struct Builder {
     if (!opt.force_generic && S == 1 && p2 && N > 4096) {
       const int lg = lg2(N);
       const int64_t N1 = (int64_t)1 << (lg / 2), N2 = N / N1;
-      const LineKernelMeta* ma = find_line_kernel((int)N1, true, true, inverse, false, 1);
-      const LineKernelMeta* mb = find_line_kernel((int)N2, false, true, false, inverse, 0);
+      const LineKernelMeta* ma = find_line_kernel((int)N1, true, true, inverse, false, 0);
+      const LineKernelMeta* mb = find_line_kernel((int)N2, false, true, false, inverse, 2);
       if (ma && mb && N2 % ma->T == 0 && N1 % mb->T == 0) {
         int64_t chunk = (int64_t)(opt.chunk_bytes / (uint64_t)(N * 8));
         chunk = std::max<int64_t>(1, std::min(chunk, lines));
@@ -199,16 +199,21 @@ struct Builder {
           const int64_t c = std::min(chunk, lines - t0);
           Step& a = push(ST_LINES);
           a.variant = ma->id;
-          a.p[0] = src.plus(t0 * N * 8); a.p[1] = w; a.p[2] = ta; a.p[3] = tlo; a.p[4] = thi;
-          a.i[0] = c * N2 / ma->T; a.i[1] = c * N2; a.i[2] = N2; a.i[3] = N; a.i[4] = N2; a.i[5] = N; a.i[6] = 10; a.i[7] = 1023;
+          a.p[0] = src.plus(t0 * N * 8); a.p[1] = w; a.p[2] = ta;
+          a.i[0] = c * N2 / ma->T; a.i[1] = c * N2; a.i[2] = N2; a.i[3] = N; a.i[4] = N2; a.i[5] = N;
           a.f[0] = 1.0f;
           a.grid = lines_grid(*ma, a.i[0]);
           Step& b = push(ST_LINES);
           b.variant = mb->id;
-          b.p[0] = w; b.p[1] = dst.plus(t0 * N * 8); b.p[2] = tb;
-          b.i[0] = c * N1 / mb->T; b.i[1] = c * N1; b.i[2] = 1; b.i[3] = N2; b.i[4] = N1; b.i[5] = N;
+          b.p[0] = w; b.p[1] = dst.plus(t0 * N * 8); b.p[2] = tb; b.p[3] = tlo; b.p[4] = thi;
+          b.i[0] = c * N1 / mb->T; b.i[1] = c * N1; b.i[2] = 1; b.i[3] = N2; b.i[4] = N1; b.i[5] = N; b.i[6] = 10; b.i[7] = 1023;
           b.f[0] = scale;
           b.grid = lines_grid(*mb, b.i[0]);
+          // four-step roots e^{-2 pi i k1 n2/N} enter at pass B's loads; with a grid that is a multiple of the
+          // tiles per transform every workgroup keeps the same rows k1 and computes its roots once per launch
+          const int64_t tpt = N1 / mb->T;
+          if ((int64_t)b.grid >= tpt) b.grid = (unsigned)((b.grid / tpt) * tpt);
+          b.i[8] = N1;
         }
         ir.route += "two-pass[N=" + std::to_string(N1) + "x" + std::to_string(N2) + ",chunk=" + std::to_string(chunk) + "] ";
         return MI355FFT_OK;
