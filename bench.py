@@ -102,6 +102,41 @@ def cpu_baseline(n, seconds_target=12.0):
             "sample": f"{sample} transforms of N={n} x {rounds} rounds in {dt_total:.1f}s, oracle/oracle.c fft1d_ref (radix-2, f32 storage, f64 twiddles), {threads} pthreads"}
 
 
+def pmc_traffic(workload):
+    """HBM bytes per step from the committed PMC passes (profiles/r*_pmc_traffic_<workload>.json), newest round"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_{workload}.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("hbm_bytes_per_step"), os.path.relpath(files[-1], ROOT)
+
+
+def time_single_pass(mi355fft, dev, ev, opts, inp, out, which, reps):
+    """live hipEvent timing of ONE of the two pass kernels (MI355FFT_ONLY_PASS planner aid): avg us per launch"""
+    os.environ["MI355FFT_ONLY_PASS"] = str(which)
+    try:
+        plan = mi355fft.createPlan(dev, opts)
+    finally:
+        del os.environ["MI355FFT_ONLY_PASS"]
+    _, launches = plan.describe()
+    enc = dev.createCommandEncoder()
+    plan.exec(enc, {"input": inp, "output": out})
+    cmds = enc.finish(use_graph=False)
+    dev.queue.submit([cmds])
+    dev.queue.onSubmittedWorkDone()
+    a, b = ev.create(), ev.create()
+    ev.record(a, dev.stream)
+    for _ in range(reps):
+        dev.queue.submit([cmds])
+    ev.record(b, dev.stream)
+    ms = ev.elapsed_ms(a, b)
+    cmds.release()
+    plan.destroy()
+    return ms * 1e3 / (reps * max(launches, 1)), launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +206,20 @@ def main():
     # MAX over ranks of the wall time around the K steps (and of the device-event time)
     wall_max, dev_max = group.reduce_max([wall, dev_ms / 1e3])
 
+    per_kernel = None
+    if rank == 0 and "two-pass" in route:
+        # per-kernel averages, measured live with hipEvents on the library's stream (must agree with the rocprofv3
+        # kernel-trace summary committed under profiles/).  Pass B alone reads whatever pass A left in the workspace.
+        ua, la = time_single_pass(mi355fft, dev, ev, opts, inp, out, 1, 3)
+        ub, lb = time_single_pass(mi355fft, dev, ev, opts, inp, out, 2, 3)
+        pts_launch = float(n) * batch / max(la, 1)
+        per_kernel = [
+            {"kernel": "fft_lines_kernel PASS_A (column FFT, N1=%d)" % (1 << (n.bit_length() - 1) // 2), "avg_launch_us": ua, "launches_per_step": la,
+             "moved_bytes_per_launch": 16 * pts_launch, "moved_GBps": 16 * pts_launch / ua / 1e3},
+            {"kernel": "fft_lines_kernel PASS_B (twiddle + row FFT + transposed store)", "avg_launch_us": ub, "launches_per_step": lb,
+             "moved_bytes_per_launch": 16 * pts_launch, "moved_GBps": 16 * pts_launch / ub / 1e3},
+        ]
+
     if rank == 0:
         points_per_step = float(n) * batch * world
         ms_per_step = wall_max / args.steps * 1e3
@@ -178,6 +227,7 @@ def main():
         # roofline of the transform on ONE GPU: algorithmic bytes of a step / device time of a step (hip events)
         step_dev_s = dev_max / args.steps
         achieved = bytes_per_point * float(n) * batch / step_dev_s / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload)
         line = {
             "metric": "1D c2c f32 GPoints/s at N=2^20 batch=4096" if args.workload == "c2c_2p20_b4096" else f"GPoints/s ({args.workload})",
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -188,11 +238,15 @@ def main():
                        "launches_per_step": launches, "executor": "op-list replay" if args.no_graph else "hipGraph replay",
                        "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "fft_lines_kernel (pass A + pass B per chunk)" if "two-pass" in route else "fft_lines_kernel",
                          "algorithmic_bytes_per_point": bytes_per_point, "device_ms_per_step": step_dev_s * 1e3,
                          "avg_launch_us": step_dev_s * 1e6 / max(launches, 1)},
         }
+        if per_kernel:
+            line["roofline"]["per_kernel"] = per_kernel
+            line["roofline"]["note"] = ("a launch in the roofline sense is the pass A + pass B pair that moves each point in and out once: "
+                                        "algorithmic 16 B/point over the pair; each pass alone moves 16 B/point through the fabric")
         if not args.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(n)

@@ -70,6 +70,7 @@ PlannerOptions planner_options_from_env() {
   PlannerOptions o;
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   return o;
 }
 
@@ -197,12 +198,15 @@ struct Builder {
         const PtrRef tlo = add_table(lo), thi = add_table(hi);
         for (int64_t t0 = 0; t0 < lines; t0 += chunk) {
           const int64_t c = std::min(chunk, lines - t0);
+          if (opt.only_pass != 2) {
           Step& a = push(ST_LINES);
           a.variant = ma->id;
           a.p[0] = src.plus(t0 * N * 8); a.p[1] = w; a.p[2] = ta;
           a.i[0] = c * N2 / ma->T; a.i[1] = c * N2; a.i[2] = N2; a.i[3] = N; a.i[4] = N2; a.i[5] = N;
           a.f[0] = 1.0f;
           a.grid = lines_grid(*ma, a.i[0]);
+          }
+          if (opt.only_pass == 1) continue;
           Step& b = push(ST_LINES);
           b.variant = mb->id;
           b.p[0] = w; b.p[1] = dst.plus(t0 * N * 8); b.p[2] = tb; b.p[3] = tlo; b.p[4] = thi;

@@ -71,6 +71,7 @@ struct PlannerOptions {
   uint64_t chunk_bytes = 1ull << 30;   // two-pass: bytes of inter-pass intermediate per launch pair (measured: larger is faster)
   int compute_units = 256;
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
+  int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };
 PlannerOptions planner_options_from_env();
 
