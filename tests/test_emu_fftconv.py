@@ -129,6 +129,7 @@ def test_fftconv_cfg4_preset_against_golden(manifest, oracle):
     sentinel = np.empty(2 * out_elems, np.float32)
     sentinel[0::2], sentinel[1::2] = 77.0, -55.0
     got, route, launches = emu.run_plan(desc, phys_in, sentinel.size, kernel=kern, out_init=sentinel)
+    assert route.startswith("fftconv-fused[N=256,K=3") and launches == 1      # the reference: ~K*(3 plans x 3 passes) + per-element copies
     gold = np.fromfile(os.path.join(GOLDEN, c["out_file"]), dtype=np.float32).reshape(K, batch, 2 * n)
     want = sentinel.copy()
     for k in range(K):
@@ -143,3 +144,26 @@ def test_fftconv_cfg4_preset_against_golden(manifest, oracle):
             lanes[lane:lane + n] = True
     assert oracle.rel_l2(got.reshape(-1, 2)[lanes], want.reshape(-1, 2)[lanes]) < 1e-5
     assert np.array_equal(got.reshape(-1, 2)[~lanes], sentinel.reshape(-1, 2)[~lanes])
+
+
+@pytest.mark.parametrize("n,K,batch,mode,layout,klen", [(64, 2, 3, "correlation", "batch-major", 64), (128, 5, 2, "convolution", "kernel-major", 128),
+                                                         (256, 15, 2, "convolution", "batch-major", 256), (512, 1, 5, "correlation", "kernel-major", 7),
+                                                         (1024, 3, 2, "convolution", "kernel-major", 100)])
+def test_fftconv_fused_matches_composed_route_and_oracle(oracle, n, K, batch, mode, layout, klen):
+    x = oracle.random_complex_interleaved(n * batch, 900 + n)
+    kern = oracle.random_complex_interleaved(klen * K, 901 + n)
+    opts = {"type": "fftconv", "shape": [n], "batch": batch, "fftConv": {"mode": mode, "kernelCount": K, "outputLayout": layout, "kernelShape": [klen]}}
+    desc, _ = _desc(opts)
+    fused, route, launches = emu.run_plan(desc, x, 2 * n * batch * K, kernel=kern)
+    assert route.startswith("fftconv-fused[") and launches == 1
+    composed, route2, launches2 = emu.run_plan(desc, x, 2 * n * batch * K, kernel=kern, force_generic=True)
+    assert "fftconv[K=" in route2 and launches2 > 1
+    assert oracle.rel_l2(fused, composed) < 2e-6
+    want = np.empty((K, batch, 2 * n), np.float32)
+    for k in range(K):
+        ref, _ = oracle.fftconv_ref(x, kern[2 * k * klen:2 * (k + 1) * klen], [n], batch, mode, "circular", [klen], use_pow2=True)
+        want[k] = ref.reshape(batch, 2 * n)
+    if layout == "batch-major":
+        want = want.transpose(1, 0, 2)
+    _close(fused, want.reshape(-1), 4e-3, 4e-3, f"fused N={n} K={K}")
+    assert oracle.rel_l2(fused, want.reshape(-1)) < 1e-5

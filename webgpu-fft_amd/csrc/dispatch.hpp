@@ -8,6 +8,7 @@
 //   template <class... P, class... A> void launch(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args);
 //   void copy(void* dst, const void* src, size_t bytes);
 #pragma once
+#include "kern_fftconv.hpp"
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
 #include "plan.hpp"
@@ -52,6 +53,20 @@ inline int family_of_line_kernel(const LineKernelMeta& m) {
   if (m.in_col && m.out_col) return FAM_PASS_A;
   if (!m.in_col && m.out_col) return FAM_PASS_B;
   return row_family(m.N);
+}
+
+template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, unsigned grid, L& l) {
+  int cur = 0;
+#define X(N, R0, R1, TL)                                                                               \
+  if (id == cur++) {                                                                                   \
+    using C = ConvCfg<N, R0, R1, TL>;                                                                  \
+    l.launch(fftconv_fused_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a);        \
+    return true;                                                                                       \
+  }
+  MI355_CONV_KERNEL_LIST(X)
+#undef X
+  (void)cur;
+  return false;
 }
 
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
@@ -128,6 +143,15 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) 
       if (s.kind == ST_GATHER) l.launch(strided_copy_kernel<true>, s.grid, 256u, 0u, a);
       else l.launch(strided_copy_kernel<false>, s.grid, 256u, 0u, a);
       return true;
+    }
+    case ST_FFTCONV_FUSED: {
+      FusedConvArgs a{};
+      a.in = (const cf*)ptr[0]; a.kern = (const cf*)ptr[1]; a.out = (cf*)ptr[2]; a.tw = (const cf*)ptr[3];
+      a.batch = s.i[0]; a.K = (int)s.i[1]; a.kern_len = (int)s.i[2]; a.conj_kernel = (int)s.i[3];
+      a.in_offset = s.i[4]; a.in_batch_stride = s.i[5]; a.in_stride = s.i[6];
+      a.out_offset = s.i[7]; a.out_kernel_stride = s.i[8]; a.out_batch_stride = s.i[9]; a.out_stride = s.i[10];
+      a.scale = s.f[0];
+      return launch_fftconv_fused(s.variant, a, s.grid, l);
     }
     case ST_ZERO:
       l.launch(zero_kernel, s.grid, 256u, 0u, (float*)ptr[0], (long long)s.i[0]);

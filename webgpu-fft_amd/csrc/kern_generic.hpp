@@ -80,20 +80,28 @@ struct R2cPostArgs {
   long long x_line_stride;  // elements between packed lines (H+1 when dense)
   float scale;
 };
+// one lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2: every Z is read once
+//   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
 static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
-  const long long per = a.H + 1;
+  const long long per = a.H / 2 + 1;
   const long long total = a.batch * per;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / per, k = g - b * per;
     const cf* z = a.z + b * a.H;
-    const cf zk = z[k == a.H ? 0 : k];
-    const cf zm = z[k == 0 || k == a.H ? 0 : a.H - k];
+    cf* x = a.x + b * a.x_line_stride;
+    const long long km = k == 0 ? 0 : a.H - k;
+    const cf zk = z[k];
+    const cf zm = z[km];
     const cf zmc = {zm.x, -zm.y};
-    const cf e = (zk + zmc) * 0.5f;       // spectrum of the even samples
-    const cf d = (zk - zmc) * 0.5f;       // i * spectrum of the odd samples
-    const cf od = mul_neg_i(d);           // spectrum of the odd samples
-    const cf r = e + cmul(a.tw[k], od);
-    a.x[b * a.x_line_stride + k] = r * a.scale;
+    const cf e = (zk + zmc) * 0.5f;
+    const cf od = mul_neg_i((zk - zmc) * 0.5f);
+    const cf wo = cmul(a.tw[k], od);
+    const cf xk = (e + wo) * a.scale;
+    cf xm = (e - wo) * a.scale;
+    xm.y = -xm.y;
+    x[k] = xk;
+    if (k == 0) x[a.H] = xm;            // X[H] = E[0] - O[0]
+    else if (km != k) x[km] = xm;
   }
 }
 
@@ -106,18 +114,25 @@ struct C2rPreArgs {
   long long H, batch;
   long long x_line_stride;
 };
+// pair form: Z[k] = E + i O and Z[H-k] = conj(E) + i conj(O) from (X[k], X[H-k]), k = 0..H/2
 static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
-  const long long total = a.batch * a.H;
+  const long long per = a.H / 2 + 1;
+  const long long total = a.batch * per;
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const long long b = g / a.H, k = g - b * a.H;
+    const long long b = g / per, k = g - b * per;
     const cf* x = a.x + b * a.x_line_stride;
+    cf* z = a.z + b * a.H;
     cf xk = x[k];
     cf xm = x[a.H - k];
-    if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }
+    if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
     const cf xmc = {xm.x, -xm.y};
     const cf e = xk + xmc;
     const cf o = cmul_conj(xk - xmc, a.tw[k]);   // * e^{+2 pi i k/N}
-    a.z[g] = e + mul_pos_i(o);
+    z[k] = e + mul_pos_i(o);
+    if (k != 0 && a.H - k != k) {
+      const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};
+      z[a.H - k] = ec + mul_pos_i(oc);
+    }
   }
 }
 

@@ -66,6 +66,18 @@ const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool sw
   return nullptr;
 }
 
+const std::vector<ConvKernelMeta>& conv_kernel_registry() {
+  static const std::vector<ConvKernelMeta> reg = [] {
+    std::vector<ConvKernelMeta> r;
+    int id = 0;
+#define X(N, R0, R1, TL) r.push_back(ConvKernelMeta{id++, N, R0, R1, TL});
+    MI355_CONV_KERNEL_LIST(X)
+#undef X
+    return r;
+  }();
+  return reg;
+}
+
 PlannerOptions planner_options_from_env() {
   PlannerOptions o;
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
@@ -383,7 +395,7 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     Step& st = b.push(ST_R2C_POST);
     st.p[0] = z; st.p[1] = out; st.p[2] = b.add_table(tw);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = b.generic_grid(lines * P);
+    st.grid = b.generic_grid(lines * (H / 2 + 1));
     b.ir.route += "r2c-split ";
   } else {
     PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
@@ -436,7 +448,7 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     Step& st = b.push(ST_C2R_PRE);
     st.p[0] = packed; st.p[1] = z; st.p[2] = b.add_table(tw);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = b.generic_grid(lines * H);
+    st.grid = b.generic_grid(lines * (H / 2 + 1));
     // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
     int rc = b.emit_axis(z, out, H, 1, lines, true, scale, err);
     if (rc) return rc;
@@ -494,6 +506,33 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     b.ir.out_bytes = strided_extent_elems(d.output, os, rank, B, (K - 1) * kstride) * 8;
   } else b.ir.out_bytes = (uint64_t)K * B * oN * 8;
 
+  // small 1-D circular problems: one launch, one workgroup per batch entry (kern_fftconv.hpp)
+  if (!b.opt.force_generic && rank == 1 && d.conv_boundary == MI355FFT_CIRCULAR && K <= 15) {
+    const ConvKernelMeta* cm = nullptr;
+    for (const auto& m : conv_kernel_registry())
+      if (m.N == fN && m.TL >= K + 1 && (!cm || m.TL < cm->TL)) cm = &m;
+    if (cm) {
+      std::vector<float2h> tw;
+      for (int q = 1; q < cm->R1; ++q) for (int k = 0; k < cm->R0; ++k) tw.push_back(root_of_unity((int64_t)q * k, fN));
+      Step& st = b.push(ST_FFTCONV_FUSED);
+      st.variant = cm->id;
+      st.p[0] = in; st.p[1] = kern; st.p[2] = out; st.p[3] = b.add_table(tw);
+      st.i[0] = B; st.i[1] = K; st.i[2] = ks[0]; st.i[3] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0;
+      st.i[4] = d.input.strided ? d.input.offset_elements : 0;
+      st.i[5] = (d.input.strided && d.input.batch_stride_elements > 0) ? d.input.batch_stride_elements : inN;
+      st.i[6] = d.input.strided ? d.input.strides[0] : 1;
+      if (d.output.strided) {
+        st.i[7] = d.output.offset_elements; st.i[8] = kstride;
+        st.i[9] = d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : oN;
+        st.i[10] = d.output.strides[0];
+      } else if (d.conv_output_layout == MI355FFT_KERNEL_MAJOR) { st.i[7] = 0; st.i[8] = B * oN; st.i[9] = oN; st.i[10] = 1; }
+      else { st.i[7] = 0; st.i[8] = oN; st.i[9] = K * oN; st.i[10] = 1; }
+      st.f[0] = (float)(1.0 / (double)fN);
+      st.grid = (unsigned)std::min<int64_t>(B, (int64_t)b.opt.compute_units * 4);
+      b.ir.route += "fftconv-fused[N=" + std::to_string(fN) + ",K=" + std::to_string(K) + ",TL=" + std::to_string(cm->TL) + "] ";
+      return MI355FFT_OK;
+    }
+  }
   const bool embed = d.conv_boundary != MI355FFT_CIRCULAR;
   mi355fft_side_layout dense{};  // strided == 0
   // 1. kernels: zero-padded into the FFT domain, transformed once per exec

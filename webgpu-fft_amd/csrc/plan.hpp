@@ -32,6 +32,13 @@ struct LineKernelMeta {
 const std::vector<LineKernelMeta>& line_kernel_registry();
 const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool swap_in, bool swap_out, int twid);
 
+// fused single-launch fftconv kernels (kern_fftconv.hpp): X(N, R0, R1, TL)
+#define MI355_CONV_KERNEL_LIST(X) \
+  X(64, 8, 8, 4) X(64, 8, 8, 16) X(128, 16, 8, 4) X(128, 16, 8, 16) X(256, 16, 16, 4) X(256, 16, 16, 16) \
+  X(512, 32, 16, 4) X(512, 32, 16, 16) X(1024, 32, 32, 4) X(1024, 32, 32, 16)
+struct ConvKernelMeta { int id, N, R0, R1, TL; };
+const std::vector<ConvKernelMeta>& conv_kernel_registry();
+
 enum BufId : int { BUF_NONE = -1, BUF_INPUT = 0, BUF_OUTPUT = 1, BUF_WORK = 2, BUF_KERNEL = 3, BUF_TABLE = 4 };
 struct PtrRef {
   int buf = BUF_NONE;
@@ -44,7 +51,7 @@ struct PtrRef {
 
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
-  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED
 };
 
 // One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).
