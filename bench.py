@@ -156,7 +156,7 @@ def main():
     group = Group("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; barrier + scalar reductions only
 
     typ, n, batch, bytes_per_point, desc = WORKLOADS[args.workload]
-    dev = mi355fft.Device(local_rank, use_graph=not args.no_graph)
+    dev = mi355fft.Device(local_rank, use_graph=False if args.no_graph else "auto")
     info = dev.info()
     if typ == "c2c":
         in_bytes = out_bytes = n * batch * 8
@@ -235,7 +235,7 @@ def main():
             "dtype": "f32", "data": "synthetic (device-side seeded PRNG twin of the oracle, uniform (-0.5,0.5), resident in HBM)",
             "config": {"workload": desc, "type": typ, "N": n, "batch_per_gpu": batch, "global_batch": batch * world,
                        "sharding": f"batch-sharded x{world}, no data-path collective", "route": route.strip(),
-                       "launches_per_step": launches, "executor": "op-list replay" if args.no_graph else "hipGraph replay",
+                       "launches_per_step": launches, "executor": "op-list replay" if (args.no_graph or launches < 8) else "hipGraph replay",
                        "arch": info["arch"], "compute_units": info["compute_units"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,

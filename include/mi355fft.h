@@ -145,8 +145,9 @@ int mi355fft_plan_describe(const mi355fft_plan* plan, char* text, size_t text_by
 int mi355fft_encoder_begin(mi355fft_device* dev, mi355fft_encoder** out);
 int mi355fft_encoder_copy_buffer(mi355fft_encoder* enc, mi355fft_buffer* src, uint64_t src_offset, mi355fft_buffer* dst,
                                  uint64_t dst_offset, uint64_t bytes);
-/* finish() consumes the encoder.  use_graph != 0 instantiates the recorded launches as a hipGraph
- * (the "hipGraph stage executor"); 0 keeps an op list that submit replays onto the stream. */
+/* finish() consumes the encoder.  use_graph: 1 instantiates the recorded launches as a hipGraph (the "hipGraph
+ * stage executor"); 0 keeps an op list that submit replays onto the stream; 2 = auto (graph for lists of >= 8
+ * launches, op list below: a single launch replays faster as a plain launch). */
 int mi355fft_encoder_finish(mi355fft_encoder* enc, int use_graph, mi355fft_commands** out);
 int mi355fft_encoder_discard(mi355fft_encoder* enc);
 /* queue.submit: enqueues; returns without waiting.  WebGPU command buffers are single-use; here a

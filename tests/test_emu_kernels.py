@@ -84,6 +84,18 @@ def test_c2c_generic_route_matches_lines_route(oracle):
     check(a, b, "routes agree", 2e-6)
 
 
+@pytest.mark.parametrize("shape", [[16, 64], [32, 128, 2], [64, 64]])
+def test_c2c_nd_column_line_kernels(oracle, shape):
+    """axes with stride S > 1 and S % 16 == 0 run the column line kernels instead of global stages"""
+    n, batch = int(np.prod(shape)), 2
+    x = oracle.random_complex_batch(n, batch, 0xD100 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc = _abi.make_desc("c2c", shape, batch, direction, "backward")
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert "columns[" in route
+        check(got, oracle.c2c_ref_batch(x, shape, batch, direction, "backward"), f"nd columns {shape} {direction}")
+
+
 @pytest.mark.parametrize("shape", [[8, 4], [16, 16], [4, 8, 2], [12, 5], [64, 3, 2]])
 def test_c2c_nd(oracle, shape):
     n, batch = int(np.prod(shape)), 2

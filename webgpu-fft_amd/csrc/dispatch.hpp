@@ -36,7 +36,8 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
   MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, true, true, 0)
 #define LINE_PASS_A(N, R0, R1, R2, T)                               \
   MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 0) \
-  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 0)
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 0)  \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, true, 0)
 #define LINE_PASS_B(N, R0, R1, R2, T)                                \
   MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, false, 2) \
   MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, true, 2)
@@ -103,15 +104,15 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) 
     }
     case ST_R2C_POST: {
       R2cPostArgs a{};
-      a.z = (const cf*)ptr[0]; a.x = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
-      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2]; a.scale = s.f[0];
+      a.z = (const cf*)ptr[0]; a.x = (cf*)ptr[1]; a.tw_lo = (const cf*)ptr[2]; a.tw_hi = (const cf*)ptr[3];
+      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2]; a.scale = s.f[0]; a.shift = (int)s.i[3]; a.mask = (unsigned)s.i[4];
       l.launch(r2c_post_kernel, s.grid, 256u, 0u, a);
       return true;
     }
     case ST_C2R_PRE: {
       C2rPreArgs a{};
-      a.x = (const cf*)ptr[0]; a.z = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
-      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2];
+      a.x = (const cf*)ptr[0]; a.z = (cf*)ptr[1]; a.tw_lo = (const cf*)ptr[2]; a.tw_hi = (const cf*)ptr[3];
+      a.H = s.i[0]; a.batch = s.i[1]; a.x_line_stride = s.i[2]; a.shift = (int)s.i[3]; a.mask = (unsigned)s.i[4];
       l.launch(c2r_pre_kernel, s.grid, 256u, 0u, a);
       return true;
     }

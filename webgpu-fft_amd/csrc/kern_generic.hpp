@@ -74,28 +74,36 @@ static __global__ void __launch_bounds__(256) scale_kernel(float* data, long lon
 // X[b][k], k = 0..H (H+1 bins per line, reference packing docs/API.md "R2C/C2R packing"):
 //   X[k] = (Z[k] + conj(Z[H-k]))/2 - (i/2) e^{-2 pi i k/N} (Z[k] - conj(Z[H-k])),  Z[H] := Z[0]
 // tw[k] = e^{-2 pi i k/N}, k <= H/2 suffices but the table holds k < H+1.
+// The root e^{-2 pi i k/N} is formed as HI[k >> shift] * LO[k & mask] from two small cache-resident tables, not
+// read from an (N/2+1)-entry table: at N = 2^22 that table would add 4 B per complex point of fabric traffic.
 struct R2cPostArgs {
-  const cf* z; cf* x; const cf* tw;
+  const cf* z; cf* x; const cf* tw_lo; const cf* tw_hi;
   long long H, batch;
   long long x_line_stride;  // elements between packed lines (H+1 when dense)
   float scale;
+  int shift; unsigned mask;
 };
-// one lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2: every Z is read once
+// Work item = (line b, chunk of 256 consecutive k): the divisions are wave-uniform (scalar), lanes walk k.
+// One lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2, so every Z is read once:
 //   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
 static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
   const long long per = a.H / 2 + 1;
-  const long long total = a.batch * per;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const long long b = g / per, k = g - b * per;
+  const long long chunks = (per + 255) / 256;
+  const long long items = a.batch * chunks;
+  for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+    const long long b = it / chunks;
+    const long long k = (it - b * chunks) * 256 + threadIdx.x;
+    if (k >= per) continue;
     const cf* z = a.z + b * a.H;
     cf* x = a.x + b * a.x_line_stride;
     const long long km = k == 0 ? 0 : a.H - k;
     const cf zk = z[k];
     const cf zm = z[km];
+    const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
     const cf zmc = {zm.x, -zm.y};
     const cf e = (zk + zmc) * 0.5f;
     const cf od = mul_neg_i((zk - zmc) * 0.5f);
-    const cf wo = cmul(a.tw[k], od);
+    const cf wo = cmul(w, od);
     const cf xk = (e + wo) * a.scale;
     cf xm = (e - wo) * a.scale;
     xm.y = -xm.y;
@@ -109,25 +117,30 @@ static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs 
 // by the full-length convention: the 1/2 of the split is absorbed):
 //   E[k] = (X[k] + conj(X[H-k])),  O[k] = (X[k] - conj(X[H-k])) e^{+2 pi i k/N},  Z[k] = E[k] + i O[k]
 // The imaginary parts of X[0] and X[H] are ignored (Hermitian unpack: real_complex.js:147-155,194-197).
+// Pair form: Z[k] = E + i O and Z[H-k] = conj(E) + i conj(O) from (X[k], X[H-k]), k = 0..H/2.
 struct C2rPreArgs {
-  const cf* x; cf* z; const cf* tw;   // tw[k] = e^{-2 pi i k/N}
+  const cf* x; cf* z; const cf* tw_lo; const cf* tw_hi;
   long long H, batch;
   long long x_line_stride;
+  int shift; unsigned mask;
 };
-// pair form: Z[k] = E + i O and Z[H-k] = conj(E) + i conj(O) from (X[k], X[H-k]), k = 0..H/2
 static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
   const long long per = a.H / 2 + 1;
-  const long long total = a.batch * per;
-  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-    const long long b = g / per, k = g - b * per;
+  const long long chunks = (per + 255) / 256;
+  const long long items = a.batch * chunks;
+  for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+    const long long b = it / chunks;
+    const long long k = (it - b * chunks) * 256 + threadIdx.x;
+    if (k >= per) continue;
     const cf* x = a.x + b * a.x_line_stride;
     cf* z = a.z + b * a.H;
     cf xk = x[k];
     cf xm = x[a.H - k];
     if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
+    const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
     const cf xmc = {xm.x, -xm.y};
     const cf e = xk + xmc;
-    const cf o = cmul_conj(xk - xmc, a.tw[k]);   // * e^{+2 pi i k/N}
+    const cf o = cmul_conj(xk - xmc, w);   // * e^{+2 pi i k/N}
     z[k] = e + mul_pos_i(o);
     if (k != 0 && a.H - k != k) {
       const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};

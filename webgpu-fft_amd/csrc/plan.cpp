@@ -46,7 +46,8 @@ const std::vector<LineKernelMeta>& line_kernel_registry() {
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, true, true, 0));
 #define LINE_PASS_A(N, R0, R1, R2, T)                                        \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 0)); \
-  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 0));
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 0));  \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, true, 0));
 #define LINE_PASS_B(N, R0, R1, R2, T)                                         \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, false, 2)); \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, true, 2));
@@ -159,6 +160,15 @@ struct Builder {
     return add_table(t);
   }
 
+  // e^{-2 pi i k/M} for k < count as HI[k >> 10] * LO[k & 1023]: tables into slots p[2] (LO), p[3] (HI), i[3] shift, i[4] mask
+  void split_roots(Step& st, int64_t M, int64_t count) {
+    std::vector<float2h> lo(1024), hi((size_t)((count + 1023) >> 10));
+    for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, M);
+    for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, M);
+    const PtrRef plo = add_table(lo), phi = add_table(hi);   // add_table may reallocate ir.steps? no: tables live in ir.table
+    st.p[2] = plo; st.p[3] = phi; st.i[3] = 10; st.i[4] = 1023;
+  }
+
   unsigned lines_grid(const LineKernelMeta& m, int64_t tiles) const {
     int64_t per_cu = 8;
     if (m.lds_bytes > 0) per_cu = std::min<int64_t>(per_cu, (160 * 1024) / m.lds_bytes);
@@ -190,6 +200,21 @@ struct Builder {
         st.f[0] = scale;
         st.grid = lines_grid(*m, tiles);
         ir.route += "lines[N=" + std::to_string(N) + "] ";
+        return MI355FFT_OK;
+      }
+    }
+    if (!opt.force_generic && S > 1 && p2) {
+      // an axis with stride S > 1 (N-D transforms): T adjacent lines form a column tile
+      const LineKernelMeta* m = find_line_kernel((int)N, true, true, inverse, inverse, 0);
+      if (m && S % m->T == 0) {
+        Step& st = push(ST_LINES);
+        st.variant = m->id;
+        st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m);
+        const int64_t tiles = lines / m->T;
+        st.i[0] = tiles; st.i[1] = lines; st.i[2] = S; st.i[3] = S * N; st.i[4] = S; st.i[5] = S * N;
+        st.f[0] = scale;
+        st.grid = lines_grid(*m, tiles);
+        ir.route += "columns[N=" + std::to_string(N) + ",S=" + std::to_string(S) + "] ";
         return MI355FFT_OK;
       }
     }
@@ -390,12 +415,11 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]
     int rc = b.emit_axis(in, z, H, 1, lines, false, 1.0f, err);
     if (rc) return rc;
-    std::vector<float2h> tw((size_t)(H + 1));
-    for (int64_t k = 0; k <= H; ++k) tw[(size_t)k] = root_of_unity(k, N);
     Step& st = b.push(ST_R2C_POST);
-    st.p[0] = z; st.p[1] = out; st.p[2] = b.add_table(tw);
+    st.p[0] = z; st.p[1] = out;
+    b.split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = b.generic_grid(lines * (H / 2 + 1));
+    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 255) / 256) * 256);
     b.ir.route += "r2c-split ";
   } else {
     PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
@@ -443,12 +467,11 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (N % 2 == 0) {
     const int64_t H = N / 2;
     PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
-    std::vector<float2h> tw((size_t)(H + 1));
-    for (int64_t k = 0; k <= H; ++k) tw[(size_t)k] = root_of_unity(k, N);
     Step& st = b.push(ST_C2R_PRE);
-    st.p[0] = packed; st.p[1] = z; st.p[2] = b.add_table(tw);
+    st.p[0] = packed; st.p[1] = z;
+    b.split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = b.generic_grid(lines * (H / 2 + 1));
+    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 255) / 256) * 256);
     // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
     int rc = b.emit_axis(z, out, H, 1, lines, true, scale, err);
     if (rc) return rc;

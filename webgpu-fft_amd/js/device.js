@@ -77,10 +77,12 @@ export class HipCommandEncoder {
   }
   finish(desc) {
     if (!this._h) throw new Error("command encoder already finished");
-    const useGraph = desc && desc.useGraph !== undefined ? !!desc.useGraph : this.device.useGraph;
+    // useGraph: true -> hipGraph, false -> op list, "auto" (default) -> graph for lists of >= 8 launches
+    const useGraph = desc && desc.useGraph !== undefined ? desc.useGraph : this.device.useGraph;
+    const mode = useGraph === "auto" ? 2 : (useGraph ? 1 : 0);
     const h = this._h;
     this._h = null;
-    return new HipCommandBuffer(this.device, native.encoderFinish(h, useGraph ? 1 : 0));
+    return new HipCommandBuffer(this.device, native.encoderFinish(h, mode));
   }
 }
 
@@ -123,7 +125,7 @@ export class HipDevice {
   constructor(ordinal, opts) {
     this.ordinal = ordinal | 0;
     this._h = native.deviceOpen(this.ordinal);
-    this.useGraph = !!(opts && opts.useGraph);
+    this.useGraph = opts && opts.useGraph !== undefined ? opts.useGraph : "auto";
     this.queue = new HipQueue(this);
     const info = native.deviceInfo(this._h);
     this.info = info;

@@ -86,7 +86,8 @@ class CommandEncoder:
             use_graph = self.device.use_graph
         h = ctypes.c_void_p()
         enc, self._h = self._h, None
-        _chk(lib().mi355fft_encoder_finish(enc, 1 if use_graph else 0, ctypes.byref(h)))
+        mode = 2 if use_graph == "auto" else (1 if use_graph else 0)
+        _chk(lib().mi355fft_encoder_finish(enc, mode, ctypes.byref(h)))
         return CommandBuffer(self.device, h)
 
 
@@ -109,7 +110,7 @@ class Queue:
 class Device:
     """The `device` argument of createPlan: a HIP device + its queue (stream)."""
 
-    def __init__(self, ordinal=0, use_graph=False):
+    def __init__(self, ordinal=0, use_graph="auto"):
         h = ctypes.c_void_p()
         _chk(lib().mi355fft_device_open(ordinal, ctypes.byref(h)))
         self._h = h
