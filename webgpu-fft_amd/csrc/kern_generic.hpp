@@ -87,29 +87,40 @@ struct R2cPostArgs {
 // One lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2, so every Z is read once:
 //   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
 static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
+  constexpr int U = 4;                       // k values per lane per item: 8 independent 8-byte loads in flight
   const long long per = a.H / 2 + 1;
-  const long long chunks = (per + 255) / 256;
+  const long long chunks = (per + 256 * U - 1) / (256 * U);
   const long long items = a.batch * chunks;
   for (long long it = blockIdx.x; it < items; it += gridDim.x) {
     const long long b = it / chunks;
-    const long long k = (it - b * chunks) * 256 + threadIdx.x;
-    if (k >= per) continue;
+    const long long k0 = (it - b * chunks) * (256 * U) + threadIdx.x;
     const cf* z = a.z + b * a.H;
     cf* x = a.x + b * a.x_line_stride;
-    const long long km = k == 0 ? 0 : a.H - k;
-    const cf zk = z[k];
-    const cf zm = z[km];
-    const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
-    const cf zmc = {zm.x, -zm.y};
-    const cf e = (zk + zmc) * 0.5f;
-    const cf od = mul_neg_i((zk - zmc) * 0.5f);
-    const cf wo = cmul(w, od);
-    const cf xk = (e + wo) * a.scale;
-    cf xm = (e - wo) * a.scale;
-    xm.y = -xm.y;
-    x[k] = xk;
-    if (k == 0) x[a.H] = xm;            // X[H] = E[0] - O[0]
-    else if (km != k) x[km] = xm;
+    cf zk[U], zm[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long long k = k0 + j * 256;
+      const long long kc = k < per ? k : 0;            // clamp: out-of-range lanes read bin 0 and store nothing
+      zk[j] = z[kc];
+      zm[j] = z[kc == 0 ? 0 : a.H - kc];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long long k = k0 + j * 256;
+      if (k >= per) continue;
+      const long long km = k == 0 ? 0 : a.H - k;
+      const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
+      const cf zmc = {zm[j].x, -zm[j].y};
+      const cf e = (zk[j] + zmc) * 0.5f;
+      const cf od = mul_neg_i((zk[j] - zmc) * 0.5f);
+      const cf wo = cmul(w, od);
+      const cf xk = (e + wo) * a.scale;
+      cf xm = (e - wo) * a.scale;
+      xm.y = -xm.y;
+      x[k] = xk;
+      if (k == 0) x[a.H] = xm;            // X[H] = E[0] - O[0]
+      else if (km != k) x[km] = xm;
+    }
   }
 }
 
@@ -125,26 +136,38 @@ struct C2rPreArgs {
   int shift; unsigned mask;
 };
 static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
+  constexpr int U = 4;
   const long long per = a.H / 2 + 1;
-  const long long chunks = (per + 255) / 256;
+  const long long chunks = (per + 256 * U - 1) / (256 * U);
   const long long items = a.batch * chunks;
   for (long long it = blockIdx.x; it < items; it += gridDim.x) {
     const long long b = it / chunks;
-    const long long k = (it - b * chunks) * 256 + threadIdx.x;
-    if (k >= per) continue;
+    const long long k0 = (it - b * chunks) * (256 * U) + threadIdx.x;
     const cf* x = a.x + b * a.x_line_stride;
     cf* z = a.z + b * a.H;
-    cf xk = x[k];
-    cf xm = x[a.H - k];
-    if (k == 0) { xk.y = 0.0f; xm.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
-    const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
-    const cf xmc = {xm.x, -xm.y};
-    const cf e = xk + xmc;
-    const cf o = cmul_conj(xk - xmc, w);   // * e^{+2 pi i k/N}
-    z[k] = e + mul_pos_i(o);
-    if (k != 0 && a.H - k != k) {
-      const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};
-      z[a.H - k] = ec + mul_pos_i(oc);
+    cf xk[U], xm[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long long k = k0 + j * 256;
+      const long long kc = k < per ? k : 0;
+      xk[j] = x[kc];
+      xm[j] = x[a.H - kc];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      const long long k = k0 + j * 256;
+      if (k >= per) continue;
+      cf p = xk[j], q = xm[j];
+      if (k == 0) { p.y = 0.0f; q.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
+      const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
+      const cf qc = {q.x, -q.y};
+      const cf e = p + qc;
+      const cf o = cmul_conj(p - qc, w);   // * e^{+2 pi i k/N}
+      z[k] = e + mul_pos_i(o);
+      if (k != 0 && a.H - k != k) {
+        const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};
+        z[a.H - k] = ec + mul_pos_i(oc);
+      }
     }
   }
 }

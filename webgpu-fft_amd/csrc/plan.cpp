@@ -419,7 +419,7 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     st.p[0] = z; st.p[1] = out;
     b.split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 255) / 256) * 256);
+    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
     b.ir.route += "r2c-split ";
   } else {
     PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
@@ -471,7 +471,7 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     st.p[0] = packed; st.p[1] = z;
     b.split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 255) / 256) * 256);
+    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
     // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
     int rc = b.emit_axis(z, out, H, 1, lines, true, scale, err);
     if (rc) return rc;
