@@ -106,14 +106,40 @@ def test_c2c_nd(oracle, shape):
         check(got, oracle.c2c_ref_batch(x, shape, batch, direction, "unitary"), f"nd {shape} {direction}")
 
 
-def test_unsupported_prime_is_a_clean_error():
-    desc = _abi.make_desc("c2c", [17], 1, "forward", "none")
+@pytest.mark.parametrize("n", [17, 29, 34, 97, 2039])
+def test_c2c_bluestein_lengths(oracle, n):
+    """lengths with a prime factor > 13 (the reference's own test sizes: complete.suite.js:664-676) run the chirp-z route"""
+    batch = 3
+    x = oracle.random_complex_batch(n, batch, 0xC100 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert "bluestein[" in route
+        want = oracle.c2c_ref_batch(x, [n], batch, direction, norm)
+        l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
+        assert l2 <= 1e-5 and mx <= 2e-5, f"bluestein N={n} {direction}: {l2:.2e} {mx:.2e}"
+        oracle.assert_close_elementwise(got, want, 3e-4, 3e-4, f"bluestein N={n}")
+
+
+@pytest.mark.parametrize("shape", [[17, 4], [8, 19], [5, 23, 2]])
+def test_c2c_nd_with_bluestein_axes(oracle, shape):
+    n, batch = int(np.prod(shape)), 2
+    x = oracle.random_complex_batch(n, batch, 0xD200 + n).reshape(-1)
+    desc = _abi.make_desc("c2c", shape, batch, "forward", "unitary")
+    got, route, _ = emu.run_plan(desc, x, x.size)
+    assert "bluestein[" in route
+    check(got, oracle.c2c_ref_batch(x, shape, batch, "forward", "unitary"), f"nd bluestein {shape}", 2e-5)
+
+
+def test_too_long_bluestein_axis_is_a_clean_error():
+    n = (1 << 22) + 1          # prime factors > 13 and beyond the chirp-z limit
+    desc = _abi.make_desc("c2c", [n], 1, "forward", "none")
     with pytest.raises(emu.EmuError) as e:
-        emu.run_plan(desc, np.zeros(34, np.float32), 34)
-    assert e.value.code == _abi.ERR_UNSUPPORTED and "Bluestein" in str(e.value)
+        emu.run_plan(desc, np.zeros(2 * n, np.float32), 2 * n)
+    assert e.value.code == _abi.ERR_UNSUPPORTED
 
 
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 16384, 6, 10, 12, 30, 9, 15, 21])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 16384, 6, 10, 12, 30, 9, 15, 21, 17, 34])
 def test_r2c_and_c2r(oracle, n):
     batch = 3
     x = oracle.random_real_batch(n, batch, 0xE000 + n).reshape(-1)

@@ -154,6 +154,15 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) 
       a.scale = s.f[0];
       return launch_fftconv_fused(s.variant, a, s.grid, l);
     }
+    case ST_CHIRP_PRE:
+    case ST_CHIRP_POST: {
+      ChirpArgs a{};
+      a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.chirp = (const cf*)ptr[2];
+      a.N = s.i[0]; a.M = s.i[1]; a.lines = s.i[2]; a.swap_in = (int)s.i[3]; a.swap_out = (int)s.i[4]; a.scale = s.f[0];
+      if (s.kind == ST_CHIRP_PRE) l.launch(bluestein_pre_kernel, s.grid, 256u, 0u, a);
+      else l.launch(bluestein_post_kernel, s.grid, 256u, 0u, a);
+      return true;
+    }
     case ST_ZERO:
       l.launch(zero_kernel, s.grid, 256u, 0u, (float*)ptr[0], (long long)s.i[0]);
       return true;

@@ -202,6 +202,39 @@ static __global__ void __launch_bounds__(256) unpack_hermitian_kernel(const cf* 
   }
 }
 
+// Bluestein chirp-z (reference: src/runtime/algorithms/bluestein_axis.js:59-, src/kernels/bluestein.js) for
+// lengths with a prime factor > 13:  X[k] = a[k] * sum_n (x[n] a[n]) conj(a)[k-n],  a[n] = e^{-i pi n^2/N},
+// evaluated as a circular convolution of power-of-two length M >= 2N-1 on the fast routes.
+//   pre : y[l][m] = x[l][m] * a[m] for m < N, 0 for N <= m < M      post: X[l][k] = z[l][k] * a[k] * scale
+struct ChirpArgs {
+  const cf* in; cf* out; const cf* chirp;
+  long long N, M, lines;
+  float scale;
+  int swap_in, swap_out;
+};
+static __global__ void __launch_bounds__(256) bluestein_pre_kernel(const ChirpArgs a) {
+  const long long total = a.lines * a.M;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long l = g / a.M, m = g - l * a.M;
+    cf v = {0.0f, 0.0f};
+    if (m < a.N) {
+      cf x = a.in[l * a.N + m];
+      if (a.swap_in) x = x.yx;
+      v = cmul(x, a.chirp[m]);
+    }
+    a.out[g] = v;
+  }
+}
+static __global__ void __launch_bounds__(256) bluestein_post_kernel(const ChirpArgs a) {
+  const long long total = a.lines * a.N;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long l = g / a.N, k = g - l * a.N;
+    cf v = cmul(a.in[l * a.M + k], a.chirp[k]) * a.scale;
+    if (a.swap_out) v = v.yx;
+    a.out[g] = v;
+  }
+}
+
 // data[b][i] *= (conj?) kern[i]   — frequency-domain product of fftconv (fft_conv.js:3-31)
 static __global__ void __launch_bounds__(256) pointwise_mul_kernel(const cf* data, cf* out, const cf* kern, long long L, long long total, int conj_kernel, float s) {
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {

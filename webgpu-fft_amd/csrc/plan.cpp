@@ -262,10 +262,7 @@ struct Builder {
     }
     // generic: one global-memory Stockham stage per radix
     const std::vector<int> radices = factorize_radices(N);
-    if (radices.empty()) {
-      err = "Unsupported: axis length " + std::to_string(N) + " has a prime factor outside {2,3,5,7,11,13} (Bluestein/Rader routes are not built yet)";
-      return MI355FFT_ERR_UNSUPPORTED;
-    }
+    if (radices.empty()) return emit_bluestein(src, dst, N, S, outer, inverse, scale, err);
     const int ns = (int)radices.size();
     PtrRef w0, w1;
     if (ns >= 2) w0 = alloc_work((uint64_t)lines * N * 8);
@@ -293,6 +290,93 @@ struct Builder {
     }
     ir.route += "stages[N=" + std::to_string(N) + ",S=" + std::to_string(S) + ",n=" + std::to_string(ns) + "] ";
     return MI355FFT_OK;
+  }
+
+  // Lengths with a prime factor > 13 (large_policy.js:214-228 picks Bluestein/Rader for those): chirp-z through a
+  // power-of-two circular convolution of length M >= 2N-1 on the fast routes.  Axes with stride S > 1 are
+  // transposed to contiguous lines first (two extra passes; a completeness route, not a tuned one).
+  int emit_bluestein(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, std::string& err) {
+    const int64_t lines = S * outer;
+    if (N > ((int64_t)1 << 22)) { err = "Unsupported: Bluestein axis length " + std::to_string(N) + " exceeds 2^22"; return MI355FFT_ERR_UNSUPPORTED; }
+    int64_t M = 1;
+    while (M < 2 * N - 1) M <<= 1;
+    // chirp a[n] = e^{-i pi n^2/N} = root(n^2 mod 2N, 2N);  B = FFT_M(b), b[n] = conj(a[n]) wrapped (b[M-n] = b[n])
+    std::vector<float2h> chirp((size_t)N);
+    std::vector<double> br((size_t)M, 0.0), bi((size_t)M, 0.0);
+    for (int64_t n = 0; n < N; ++n) {
+      const int64_t m = (int64_t)(((unsigned __int128)n * (unsigned __int128)n) % (unsigned __int128)(2 * N));
+      const long double ang = -3.14159265358979323846264338327950288L * (long double)m / (long double)N;
+      chirp[(size_t)n] = root_of_unity(m, 2 * N);
+      const double cr = (double)cosl(ang), ci = (double)sinl(ang);
+      br[(size_t)n] = cr; bi[(size_t)n] = -ci;
+      if (n > 0) { br[(size_t)(M - n)] = cr; bi[(size_t)(M - n)] = -ci; }
+    }
+    host_fft_pow2(br, bi);
+    std::vector<float2h> bt((size_t)M);
+    for (int64_t m = 0; m < M; ++m) bt[(size_t)m] = float2h{(float)br[(size_t)m], (float)bi[(size_t)m]};
+    const PtrRef tchirp = add_table(chirp), tb = add_table(bt);
+    PtrRef lin_src = src, lin_dst = dst;
+    PtrRef tr;   // dense [outer][S][N] copy of a strided axis
+    if (S > 1) {
+      tr = alloc_work((uint64_t)lines * N * 8);
+      Step& g = push(ST_GATHER);     // transpose [outer][N][S] -> [outer][S][N]
+      g.p[0] = src; g.p[1] = tr;
+      g.i[0] = lines * N; g.i[1] = S * N; g.i[2] = 2; g.i[3] = 0; g.i[4] = S * N; g.i[5] = 0; g.i[6] = S * N;
+      g.shape[0] = N; g.shape[1] = S; g.sa[0] = S; g.sa[1] = 1; g.sb[0] = 1; g.sb[1] = N;
+      g.grid = generic_grid(g.i[0]);
+      lin_src = tr; lin_dst = tr;
+    }
+    const PtrRef y = alloc_work((uint64_t)lines * M * 8);
+    Step& pre = push(ST_CHIRP_PRE);
+    pre.p[0] = lin_src; pre.p[1] = y; pre.p[2] = tchirp;
+    pre.i[0] = N; pre.i[1] = M; pre.i[2] = lines; pre.i[3] = inverse ? 1 : 0; pre.i[4] = 0;
+    pre.grid = generic_grid(lines * M);
+    int rc = emit_axis(y, y, M, 1, lines, false, 1.0f, err);
+    if (rc) return rc;
+    Step& pm = push(ST_POINTWISE);
+    pm.p[0] = y; pm.p[1] = y; pm.p[2] = tb;
+    pm.i[0] = M; pm.i[1] = lines * M; pm.i[2] = 0; pm.f[0] = 1.0f;
+    pm.grid = generic_grid(lines * M);
+    rc = emit_axis(y, y, M, 1, lines, true, 1.0f, err);
+    if (rc) return rc;
+    Step& post = push(ST_CHIRP_POST);
+    post.p[0] = y; post.p[1] = lin_dst; post.p[2] = tchirp;
+    post.i[0] = N; post.i[1] = M; post.i[2] = lines; post.i[3] = 0; post.i[4] = inverse ? 1 : 0;
+    post.f[0] = (float)((double)scale / (double)M);
+    post.grid = generic_grid(lines * N);
+    if (S > 1) {
+      Step& sc = push(ST_SCATTER);   // back to [outer][N][S]
+      sc.p[0] = tr; sc.p[1] = dst;
+      sc.i[0] = lines * N; sc.i[1] = S * N; sc.i[2] = 2; sc.i[3] = 0; sc.i[4] = S * N; sc.i[5] = 0; sc.i[6] = S * N;
+      sc.shape[0] = N; sc.shape[1] = S; sc.sa[0] = S; sc.sa[1] = 1; sc.sb[0] = 1; sc.sb[1] = N;
+      sc.grid = generic_grid(sc.i[0]);
+    }
+    ir.route += "bluestein[N=" + std::to_string(N) + ",M=" + std::to_string(M) + "] ";
+    return MI355FFT_OK;
+  }
+
+  // in-place radix-2 FFT in f64 (plan-time tables only)
+  static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+      size_t bit = n >> 1;
+      for (; j & bit; bit >>= 1) j ^= bit;
+      j ^= bit;
+      if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+      const size_t half = len >> 1;
+      for (size_t k = 0; k < half; ++k) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)len;
+        const double wr = (double)cosl(ang), wi = (double)sinl(ang);
+        for (size_t i = k; i < n; i += len) {
+          const size_t j = i + half;
+          const double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+          re[j] = re[i] - tr; im[j] = im[i] - ti;
+          re[i] += tr; im[i] += ti;
+        }
+      }
+    }
   }
 
   // all axes of a dense [batch][shape] complex array, src -> dst

@@ -23,7 +23,7 @@ function check(got, want, atol, rtol, what) {
   orc.assertCloseArray(got, want, atol, rtol, what);
 }
 
-for (const N of [8, 16, 128, 1024, 4096, 210, 96]) {
+for (const N of [8, 16, 34, 128, 1024, 4096, 210, 17, 29, 97, 2039]) {   // complete.suite.js:664-676 sizes (+ pow-2)
   test("c2c 1D forward/inverse N=" + N + " matches the CPU oracle", async () => {
     const dev = await ensureDevice();
     for (const direction of ["forward", "inverse"]) {
@@ -215,7 +215,7 @@ test("error behaviour: destroyed plan, missing output, in-place aliasing, offset
   assertThrows(() => q.exec(dev.createCommandEncoder(), { input: a, output: b }), /inPlace=true requires output omitted or equal to input/);
   assert(typeof q.getWorkspaceSizeBytes() === "number" && q.getPipelineCacheSnapshot().schema === "webgpufft.pipeline-cache");
   q.destroy(); a.destroy(); b.destroy();
-  assertThrows(() => fft.createPlan(dev, { type: "c2c", shape: [17], direction: "forward" }), /Bluestein|Unsupported/);
+  assertThrows(() => fft.createPlan(dev, { type: "dct2", shape: [16], direction: "forward" }), /Unsupported/);
 });
 
 run();
