@@ -151,6 +151,8 @@ def main():
     import mi355fft
     from mi355fft.sharding import Group, rank_info, shard_range
     rank, local_rank, world = rank_info()
+    if os.environ.get("MI355FFT_BENCH_SHARE_GPU"):   # rehearsal on a 1-GPU box: all ranks use device 0 (RCCL refuses, gloo takes over)
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
     group = Group("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; barrier + scalar reductions only
@@ -207,7 +209,7 @@ def main():
     wall_max, dev_max = group.reduce_max([wall, dev_ms / 1e3])
 
     per_kernel = None
-    if rank == 0 and "two-pass" in route:
+    if rank == 0 and typ == "c2c" and "two-pass" in route:
         # per-kernel averages, measured live with hipEvents on the library's stream (must agree with the rocprofv3
         # kernel-trace summary committed under profiles/).  Pass B alone reads whatever pass A left in the workspace.
         ua, la = time_single_pass(mi355fft, dev, ev, opts, inp, out, 1, 3)
@@ -259,6 +261,7 @@ def main():
     inp.destroy()
     out.destroy()
     dev.close()
+    group.barrier()   # rank 0 may still be timing the single-pass plans / CPU baseline
     group.close()
 
 

@@ -24,14 +24,26 @@ class Group:
         self.active = self.world > 1
         self.device = device
         self.dist = None
+        self.backend = None
         if self.active:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
-            kwargs = {}
-            if backend == "nccl" and device is not None:
-                kwargs["device_id"] = device
-            dist.init_process_group(backend or "gloo", **kwargs)
+            self.backend = backend or "gloo"
+            try:
+                kwargs = {}
+                if self.backend == "nccl" and device is not None:
+                    kwargs["device_id"] = device
+                dist.init_process_group(self.backend, **kwargs)
+            except Exception as e:  # RCCL unavailable (e.g. ranks sharing one GPU): the collectives here are only
+                # barriers and scalar reductions, so gloo over CPU tensors is an exact substitute
+                import sys
+                print(f"[mi355fft.sharding] {self.backend} init failed ({e}); using gloo for barriers/reductions", file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                self.backend = "gloo"
+                self.device = None
+                dist.init_process_group("gloo")
             self.dist = dist
 
     def barrier(self):
