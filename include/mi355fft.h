@@ -61,6 +61,26 @@ typedef struct mi355fft_side_layout {
   int64_t batch_stride_elements;
 } mi355fft_side_layout;
 
+/* opts.ioView.{input,output} after normalisation (runtime/ioview.js:7-37): the physical view has `shape` and sits at
+ * logical coordinate `offset` (may be negative).  Input: logical[c] = view[c - offset] inside the view, 0 outside
+ * (kernels/ioview.js generateEmbedComplexWGSL).  Output: view[v] = logical[v + offset] where that is inside the logical
+ * domain; other view elements are zeroed when clear_outside, else left untouched (generateExtractComplexWGSL). */
+typedef struct mi355fft_io_view {
+  int32_t enabled;
+  int32_t clear_outside;
+  int64_t shape[MI355FFT_MAX_RANK];
+  int64_t offset[MI355FFT_MAX_RANK];
+} mi355fft_io_view;
+
+/* opts.zeroPad.{read,write} (runtime/zero_pad.js:11-45): logical elements outside [start, end) are zeroed — read: after
+ * input load/embedding and before the transform; write: after transform + normalisation, before output extraction. */
+typedef struct mi355fft_zero_range {
+  int32_t enabled;
+  int32_t reserved;
+  int64_t start[MI355FFT_MAX_RANK];
+  int64_t end[MI355FFT_MAX_RANK];
+} mi355fft_zero_range;
+
 /* createPlan(device, opts) option object (docs/API.md:9-109), hot-path subset. */
 typedef struct mi355fft_plan_desc {
   uint32_t struct_size;            /* sizeof(mi355fft_plan_desc): ABI guard */
@@ -80,6 +100,12 @@ typedef struct mi355fft_plan_desc {
   int32_t conv_output_layout;      /* dense output: [kernel][batch][logical] or [batch][kernel][logical] */
   int64_t conv_kernel_shape[MI355FFT_MAX_RANK]; /* all 0 => same as shape */
   int64_t conv_output_kernel_stride_elements;   /* strided output: lane step per kernel (fftconv.js:868-871) */
+  /* c2c only this round: padding / embedding / range zeroing (docs/API.md "ioView", "zeroPad").  When an ioView side is
+   * enabled, that side's layout (dense or strided) describes the VIEW's physical shape. */
+  mi355fft_io_view io_input;
+  mi355fft_io_view io_output;
+  mi355fft_zero_range zero_read;
+  mi355fft_zero_range zero_write;
 } mi355fft_plan_desc;
 
 /* plan.exec(commandEncoder, {input, output?, temp?, inputOffsetBytes, outputOffsetBytes, kernel?})

@@ -1,0 +1,113 @@
+"""CPU tier: c2c ioView (pad-in-read / crop / embed-in-write, clearOutside) and zeroPad (read / write ranges)
+under host emulation, against a numpy restatement of the reference's embed / extract / zero semantics
+(src/kernels/ioview.js generateEmbedComplexWGSL / generateExtractComplexWGSL, src/kernels/zero_pad.js) around the oracle."""
+import numpy as np
+import pytest
+
+import emu_harness as emu
+from mi355fft import _abi
+from mi355fft.layout import resolve_plan_options
+
+
+def _desc(opts):
+    r = resolve_plan_options(opts)
+    return _abi.make_desc(r["type"], r["shape"], r["batch"], r["direction"], r["normalize"], r["inPlace"], r["input_layout"], r["output_layout"],
+                          r["conv"], r["io_view"], r["zero_pad"]), r
+
+
+def _as_nd(flat, shape, batch):
+    return flat.reshape(batch, *reversed(shape), 2).copy()          # axis 0 fastest -> last numpy axis before re/im
+
+
+def _box(shape, start, end):
+    return tuple(slice(start[d], end[d]) for d in reversed(range(len(shape))))
+
+
+def reference(oracle, x, shape, batch, direction, normalize, io_in=None, io_out=None, zr=None, zw=None, out_init=None):
+    rank = len(shape)
+    if io_in:
+        v = _as_nd(x, io_in["shape"], batch)
+        logical = np.zeros((batch, *reversed(shape), 2), np.float32)
+        for idx in np.ndindex(*reversed(shape)):
+            c = idx[::-1]
+            vc = [c[d] - io_in["offset"][d] for d in range(rank)]
+            if all(0 <= vc[d] < io_in["shape"][d] for d in range(rank)):
+                logical[(slice(None), *idx)] = v[(slice(None), *vc[::-1])]
+    else:
+        logical = _as_nd(x, shape, batch)
+    if zr:
+        keep = np.zeros(tuple(reversed(shape)), bool)
+        keep[_box(shape, zr["start"], zr["end"])] = True
+        logical[:, ~keep] = 0
+    y = oracle.c2c_ref_batch(logical.reshape(-1), shape, batch, direction, normalize).reshape(batch, *reversed(shape), 2)
+    if zw:
+        keep = np.zeros(tuple(reversed(shape)), bool)
+        keep[_box(shape, zw["start"], zw["end"])] = True
+        y[:, ~keep] = 0
+    if not io_out:
+        return y.reshape(-1)
+    out = _as_nd(np.asarray(out_init, np.float32), io_out["shape"], batch)
+    if io_out.get("clearOutside"):
+        out[...] = 0
+    for idx in np.ndindex(*reversed(io_out["shape"])):
+        vc = idx[::-1]
+        lc = [vc[d] + io_out["offset"][d] for d in range(rank)]
+        if all(0 <= lc[d] < shape[d] for d in range(rank)):
+            out[(slice(None), *idx)] = y[(slice(None), *lc[::-1])]
+    return out.reshape(-1)
+
+
+CASES = [
+    # (shape, ioView, zeroPad)
+    ([16], {"input": {"shape": [10]}}, None),                                                   # pad-in-read at the start
+    ([16], {"input": {"shape": [10], "placement": "center"}}, None),                            # centred
+    ([16], {"input": {"shape": [24], "offset": [-3]}}, None),                                   # view larger than the domain: crop
+    ([16], {"output": {"shape": [8], "offset": [4]}}, None),                                    # sub-region write, rest untouched
+    ([16], {"output": {"shape": [24], "placement": "center", "clearOutside": True}}, None),     # embed into a larger output, cleared
+    ([16], {"output": {"shape": [24], "placement": "center"}}, None),                           # ... or left untouched
+    ([8, 4], {"input": {"shape": [5, 3], "offset": [2, 1]}, "output": {"shape": [6, 6], "offset": [1, -1]}}, None),
+    ([16], None, {"read": {"start": [4], "end": [12]}, "write": {"start": [2], "end": [14]}}),  # the docs/API.md example
+    ([8, 4], {"input": {"shape": [6, 4]}}, {"read": {"start": [1, 0], "end": [7, 3]}}),
+    ([12, 5], None, {"write": {"start": [0, 1], "end": [12, 4]}}),
+]
+
+
+@pytest.mark.parametrize("shape,io_view,zero_pad", CASES)
+def test_c2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
+    batch = 2
+    opts = {"type": "c2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "unitary"}
+    if io_view:
+        opts["ioView"] = io_view
+    if zero_pad:
+        opts["zeroPad"] = zero_pad
+    desc, r = _desc(opts)
+    in_shape = r["io_view"]["input"]["shape"] if r["io_view"]["input"] else shape
+    out_shape = r["io_view"]["output"]["shape"] if r["io_view"]["output"] else shape
+    x = oracle.random_complex_interleaved(int(np.prod(in_shape)) * batch, 31337 + sum(shape))
+    out_floats = 2 * int(np.prod(out_shape)) * batch
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
+    got, route, _ = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    want = reference(oracle, x, shape, batch, "forward", "unitary", r["io_view"]["input"], r["io_view"]["output"],
+                     r["zero_pad"]["read"], r["zero_pad"]["write"], sentinel)
+    assert got.shape == want.shape
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, route
+
+
+def test_noop_views_resolve_to_nothing():
+    _, r = _desc({"type": "c2c", "shape": [8, 4], "direction": "forward", "ioView": {"input": {"shape": [8, 4]}, "output": {"shape": [8, 4], "offset": [0, 0]}},
+                  "zeroPad": {"read": {"start": [0, 0], "end": [8, 4]}}})
+    assert r["io_view"] == {"input": None, "output": None} and r["zero_pad"] == {"read": None, "write": None}
+
+
+def test_view_validation_messages():
+    bad = [({"ioView": {"input": {"shape": [8]}}}, "ioView.input.shape must be an array of 2 positive ints"),
+           ({"ioView": {"output": {"shape": [8, 4], "placement": "middle"}}}, 'placement must be "start"|"center"'),
+           ({"zeroPad": {"read": {"start": [0, 0], "end": [9, 4]}}}, "zeroPad.read.end[0] must be <= shape[0] (8); got 9"),
+           ({"zeroPad": {"write": {"start": [3, 0], "end": [2, 4]}}}, "zeroPad.write: start[0] must be <= end[0]")]
+    for extra, frag in bad:
+        with pytest.raises(ValueError) as e:
+            resolve_plan_options(dict({"type": "c2c", "shape": [8, 4], "direction": "forward"}, **extra))
+        assert frag in str(e.value)
+    with pytest.raises(NotImplementedError):
+        resolve_plan_options({"type": "r2c", "shape": [8], "direction": "forward", "zeroPad": {"read": {"start": [1], "end": [8]}}})

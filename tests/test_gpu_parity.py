@@ -215,6 +215,33 @@ def test_strided_layout_whdcn(fft, dev, oracle):
     check(oracle, got, want, "whdcn lanes")
 
 
+def test_c2c_ioview_and_zeropad(fft, dev, oracle):
+    """pad-in-read + embed-in-write (clearOutside) + range zeroing, checked against the emu-tier numpy restatement"""
+    from test_emu_ioview import reference
+    from mi355fft.layout import resolve_plan_options
+    shape, batch = [64, 8], 3
+    opts = {"type": "c2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "unitary",
+            "ioView": {"input": {"shape": [40, 8], "placement": "center"}, "output": {"shape": [80, 10], "placement": "center", "clearOutside": True}},
+            "zeroPad": {"read": {"start": [4, 0], "end": [60, 8]}, "write": {"start": [0, 1], "end": [64, 7]}}}
+    r = resolve_plan_options(opts)
+    x = oracle.random_complex_interleaved(40 * 8 * batch, 4711)
+    out_floats = 2 * 80 * 10 * batch
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
+    got, (route, _) = run_plan(fft, dev, opts, x, out_floats, out_init=sentinel)
+    assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
+    want = reference(oracle, x, shape, batch, "forward", "unitary", r["io_view"]["input"], r["io_view"]["output"], r["zero_pad"]["read"],
+                     r["zero_pad"]["write"], sentinel)
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * max(1.0, float(np.max(np.abs(want))))
+    # without clearOutside the surrounding elements keep their sentinel
+    opts["ioView"]["output"]["clearOutside"] = False
+    got, _ = run_plan(fft, dev, opts, x, out_floats, out_init=sentinel)
+    r = resolve_plan_options(opts)
+    want = reference(oracle, x, shape, batch, "forward", "unitary", r["io_view"]["input"], r["io_view"]["output"], r["zero_pad"]["read"],
+                     r["zero_pad"]["write"], sentinel)
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * max(1.0, float(np.max(np.abs(want))))
+    assert np.count_nonzero(got == 77.0) > 0
+
+
 # ---- r2c / c2r ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 8192, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21, 17])
 def test_r2c_c2r(fft, dev, oracle, n):

@@ -276,6 +276,26 @@ static __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedA
   }
 }
 
+// zeroPad stages (src/kernels/zero_pad.js:21-80): zero every logical element outside the box [start, end)
+struct ZeroOutsideArgs {
+  cf* data;
+  long long total, per;
+  int rank;
+  long long shape[8], start[8], end[8];
+};
+static __global__ void __launch_bounds__(256) zero_outside_kernel(const ZeroOutsideArgs a) {
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
+    long long rem = g % a.per;
+    bool inside = true;
+    for (int i = 0; i < a.rank; ++i) {
+      const long long c = rem % a.shape[i];
+      rem /= a.shape[i];
+      inside = inside && c >= a.start[i] && c < a.end[i];
+    }
+    if (!inside) { cf z = {0.0f, 0.0f}; a.data[g] = z; }
+  }
+}
+
 static __global__ void __launch_bounds__(256) zero_kernel(float* data, long long count) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) data[i] = 0.0f;
 }

@@ -457,32 +457,135 @@ int validate_common(const mi355fft_plan_desc& d, std::string& err) {
   return MI355FFT_OK;
 }
 
+// intersection of the view box [off, off+vshape) with the logical domain [0, lshape): region extent, its start in
+// logical coordinates and in view coordinates.  false when empty.
+bool view_region(const mi355fft_io_view& v, const int64_t* lshape, int rank, int64_t* ext, int64_t* lstart, int64_t* vstart) {
+  for (int i = 0; i < rank; ++i) {
+    const int64_t s = std::max<int64_t>(0, v.offset[i]), e = std::min<int64_t>(lshape[i], v.offset[i] + v.shape[i]);
+    if (e <= s) return false;
+    ext[i] = e - s; lstart[i] = s; vstart[i] = s - v.offset[i];
+  }
+  return true;
+}
+
+void emit_zero_outside(Builder& b, PtrRef data, const mi355fft_zero_range& z, const int64_t* shape, int rank, int64_t batch) {
+  Step& st = b.push(ST_ZERO_OUTSIDE);
+  st.p[0] = data;
+  const int64_t per = prodv(shape, rank);
+  st.i[0] = per * batch; st.i[1] = per; st.i[2] = rank;
+  for (int i = 0; i < rank; ++i) { st.shape[i] = shape[i]; st.sa[i] = z.start[i]; st.sb[i] = z.end[i]; }
+  st.grid = b.generic_grid(st.i[0]);
+}
+
+int validate_views(const mi355fft_plan_desc& d, std::string& err) {
+  for (const mi355fft_io_view* v : {&d.io_input, &d.io_output})
+    if (v->enabled)
+      for (int i = 0; i < d.rank; ++i)
+        if (v->shape[i] <= 0) { err = "ioView shape must be an array of positive ints"; return MI355FFT_ERR_INVALID; }
+  const char* names[2] = {"zeroPad.read", "zeroPad.write"};
+  int k = 0;
+  for (const mi355fft_zero_range* z : {&d.zero_read, &d.zero_write}) {
+    if (z->enabled)
+      for (int i = 0; i < d.rank; ++i) {
+        if (z->start[i] < 0 || z->end[i] < 0 || z->start[i] > z->end[i] || z->end[i] > d.shape[i]) {
+          err = std::string(names[k]) + ": need 0 <= start[" + std::to_string(i) + "] <= end[" + std::to_string(i) + "] <= shape[" + std::to_string(i) + "]";
+          return MI355FFT_ERR_INVALID;
+        }
+      }
+    ++k;
+  }
+  return MI355FFT_OK;
+}
+
 int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (d.direction != MI355FFT_FORWARD && d.direction != MI355FFT_INVERSE) { err = "direction must be one of \"forward\", \"inverse\""; return MI355FFT_ERR_INVALID; }
-  const bool inverse = d.direction == MI355FFT_INVERSE;
-  const int64_t n = prodv(d.shape, d.rank);
-  const float scale = (float)scale_factor(d.normalize, inverse, (double)n);
-  PtrRef in(BUF_INPUT, 0), out(d.in_place ? BUF_INPUT : BUF_OUTPUT, 0);
-  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, d.shape, d.rank, d.batch, 0) * 8 : (uint64_t)n * d.batch * 8;
-  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, d.shape, d.rank, d.batch, 0) * 8 : (uint64_t)n * d.batch * 8;
-  PtrRef src = in, dst = out;
-  if (d.input.strided) {
-    src = b.alloc_work((uint64_t)n * d.batch * 8);
-    b.emit_strided(true, in, src, d.input, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0);
-    b.ir.route += "gather ";
-  }
-  if (d.output.strided) dst = d.input.strided ? src : b.alloc_work((uint64_t)n * d.batch * 8);
-  const int rc = b.emit_nd(src, dst, d.shape, d.rank, d.batch, inverse, scale, err);
+  int rc = validate_views(d, err);
   if (rc) return rc;
-  if (d.output.strided) {
-    b.emit_strided(false, out, dst, d.output, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0);
+  const bool inverse = d.direction == MI355FFT_INVERSE;
+  const int rank = d.rank;
+  const int64_t n = prodv(d.shape, rank);
+  const float scale = (float)scale_factor(d.normalize, inverse, (double)n);
+  const bool vin = d.io_input.enabled != 0, vout = d.io_output.enabled != 0;
+  if (d.in_place && (vin || vout || d.input.strided || d.output.strided)) { err = "inPlace=true cannot be combined with ioView or strided layouts"; return MI355FFT_ERR_INVALID; }
+  const int64_t* ishape = vin ? d.io_input.shape : d.shape;     // physical shapes of the two sides
+  const int64_t* oshape = vout ? d.io_output.shape : d.shape;
+  const int64_t in_n = prodv(ishape, rank), out_n = prodv(oshape, rank);
+  PtrRef in(BUF_INPUT, 0), out(d.in_place ? BUF_INPUT : BUF_OUTPUT, 0);
+  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, ishape, rank, d.batch, 0) * 8 : (uint64_t)in_n * d.batch * 8;
+  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, oshape, rank, d.batch, 0) * 8 : (uint64_t)out_n * d.batch * 8;
+
+  // ---- input side: dense logical staging when anything but a plain dense read is asked for ----
+  PtrRef src = in;
+  const bool stage_in = d.input.strided || vin || (d.zero_read.enabled && !d.in_place);
+  if (stage_in) {
+    src = b.alloc_work((uint64_t)n * d.batch * 8);
+    if (vin) {
+      int64_t ext[8], ls[8], vs[8];
+      const bool any = view_region(d.io_input, d.shape, rank, ext, ls, vs);
+      bool covers = any;
+      for (int i = 0; any && i < rank; ++i) covers = covers && ext[i] == d.shape[i];
+      if (!covers) { Step& z = b.push(ST_ZERO); z.p[0] = src; z.i[0] = n * d.batch * 2; z.grid = b.generic_grid(z.i[0]); }
+      if (any) {
+        // physical offset of the region's first element inside the view
+        mi355fft_side_layout lay = d.input;
+        int64_t vstride = 1, poff = 0;
+        for (int i = 0; i < rank; ++i) { poff += vs[i] * (lay.strided ? lay.strides[i] : vstride); vstride *= ishape[i]; }
+        if (!lay.strided) { lay.strided = 1; int64_t st = 1; for (int i = 0; i < rank; ++i) { lay.strides[i] = st; st *= ishape[i]; } lay.offset_elements = 0; lay.batch_stride_elements = in_n; }
+        else if (lay.batch_stride_elements <= 0) lay.batch_stride_elements = in_n;
+        b.emit_strided(true, in, src, lay, ext, rank, d.batch, d.shape, ls, n, poff);
+      }
+      b.ir.route += "embed ";
+    } else if (d.input.strided) {
+      b.emit_strided(true, in, src, d.input, d.shape, rank, d.batch, d.shape, nullptr, n, 0);
+      b.ir.route += "gather ";
+    } else {
+      Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = src; c.i[0] = n * d.batch * 8;
+    }
+  }
+  if (d.zero_read.enabled) { emit_zero_outside(b, src, d.zero_read, d.shape, rank, d.batch); b.ir.route += "zero-read "; }
+
+  // ---- transform ----
+  const bool stage_out = d.output.strided || vout;
+  PtrRef dst = out;
+  if (stage_out) dst = stage_in ? src : b.alloc_work((uint64_t)n * d.batch * 8);
+  rc = b.emit_nd(src, dst, d.shape, rank, d.batch, inverse, scale, err);
+  if (rc) return rc;
+  if (d.zero_write.enabled) { emit_zero_outside(b, dst, d.zero_write, d.shape, rank, d.batch); b.ir.route += "zero-write "; }
+
+  // ---- output side ----
+  if (vout) {
+    if (d.io_output.clear_outside) {
+      if (d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
+      Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * 2; z.grid = b.generic_grid(z.i[0]);
+    }
+    int64_t ext[8], ls[8], vs[8];
+    if (view_region(d.io_output, d.shape, rank, ext, ls, vs)) {
+      mi355fft_side_layout lay = d.output;
+      int64_t vstride = 1, poff = 0;
+      for (int i = 0; i < rank; ++i) { poff += vs[i] * (lay.strided ? lay.strides[i] : vstride); vstride *= oshape[i]; }
+      if (!lay.strided) { lay.strided = 1; int64_t st = 1; for (int i = 0; i < rank; ++i) { lay.strides[i] = st; st *= oshape[i]; } lay.offset_elements = 0; lay.batch_stride_elements = out_n; }
+      else if (lay.batch_stride_elements <= 0) lay.batch_stride_elements = out_n;
+      b.emit_strided(false, out, dst, lay, ext, rank, d.batch, d.shape, ls, n, poff);
+    }
+    b.ir.route += "extract ";
+  } else if (d.output.strided) {
+    b.emit_strided(false, out, dst, d.output, d.shape, rank, d.batch, d.shape, nullptr, n, 0);
     b.ir.route += "scatter ";
   }
   return MI355FFT_OK;
 }
 
 // r2c along axis 0 (packed P = N/2+1 bins), then c2c along the remaining axes of the packed array
+int reject_views(const mi355fft_plan_desc& d, const char* what, std::string& err) {
+  if (d.io_input.enabled || d.io_output.enabled || d.zero_read.enabled || d.zero_write.enabled) {
+    err = std::string("Unsupported: ioView / zeroPad on ") + what + " are not built yet (c2c only this round)";
+    return MI355FFT_ERR_UNSUPPORTED;
+  }
+  return MI355FFT_OK;
+}
+
 int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (int rv = reject_views(d, "r2c", err)) return rv;
   if (d.direction != MI355FFT_FORWARD) { err = "r2c supports direction:\"forward\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
   if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on r2c are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
@@ -526,6 +629,7 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 }
 
 int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (int rv = reject_views(d, "c2r", err)) return rv;
   if (d.direction != MI355FFT_INVERSE) { err = "c2r supports direction:\"inverse\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
   if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on c2r are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
@@ -578,6 +682,7 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 // y_k = IFFT( FFT(x) .* (conj?)FFT(h_k) ) / Nfft, cropped per boundary, written per output layout / lanes
 // (runtime/plans/fftconv.js:308-709, exec :1415-1712; reference semantics: src/utils/math.js:469-603)
 int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (int rv = reject_views(d, "fftconv", err)) return rv;
   if (d.in_place) { err = "fftconv inPlace=true is not supported in current implementation"; return MI355FFT_ERR_INVALID; }
   if (d.conv_mode != MI355FFT_CONVOLUTION && d.conv_mode != MI355FFT_CORRELATION) { err = "fftConv.mode must be one of \"convolution\", \"correlation\""; return MI355FFT_ERR_INVALID; }
   if (d.conv_boundary < 0 || d.conv_boundary > 3) { err = "fftConv.boundary must be one of \"circular\", \"linear-full\", \"linear-same\", \"linear-valid\""; return MI355FFT_ERR_INVALID; }

@@ -242,6 +242,54 @@ function resolveChannelPolicy(layout, policy, kernelCount, inTotal, outTotal) {
 
 const isPosInt = (x) => Number.isInteger(x) && x > 0;
 
+// runtime/ioview.js:7-37; a side that maps 1:1 onto the logical domain resolves to null
+export function normalizeIoView(rank, logicalShape, ioView) {
+  const one = (v, kind) => {
+    if (!v) return null;
+    const shape = v.shape;
+    if (!Array.isArray(shape) || shape.length !== rank || !shape.every(isPosInt)) throw new Error("ioView." + kind + ".shape must be an array of " + rank + " positive ints");
+    const placement = dflt(v.placement, "start");
+    if (placement !== "start" && placement !== "center") throw new Error("ioView." + kind + '.placement must be "start"|"center"');
+    let offset = v.offset;
+    if (offset != null) {
+      if (!Array.isArray(offset) || offset.length !== rank || !offset.every((x) => Number.isInteger(x))) throw new Error("ioView." + kind + ".offset must be an array of " + rank + " integers");
+      offset = offset.slice();
+    } else if (placement === "center") offset = shape.map((s, d) => Math.floor((logicalShape[d] - s) / 2));
+    else offset = new Array(rank).fill(0);
+    if (arraysEqual(shape, logicalShape) && offset.every((o) => o === 0)) return null;
+    return { shape: shape.slice(), offset, clearOutside: kind === "output" ? !!v.clearOutside : false };
+  };
+  const iv = ioView || {};
+  return { input: one(iv.input, "input"), output: one(iv.output, "output") };
+}
+
+// runtime/zero_pad.js:11-45; a stage covering the whole domain resolves to null
+export function normalizeZeroPad(rank, shape, zeroPad, name) {
+  const nm0 = name || "zeroPad";
+  if (!zeroPad) return { read: null, write: null };
+  if (typeof zeroPad !== "object") throw new Error(nm0 + " must be an object with optional read/write stage configs");
+  const stage = (st, nm) => {
+    if (!st) return null;
+    if (typeof st !== "object") throw new Error(nm + " must be an object with optional start/end arrays");
+    const src = st.range && typeof st.range === "object" ? st.range : st;
+    const bound = (v, which, d) => {
+      if (v == null) return d.slice();
+      if (!Array.isArray(v) || v.length !== rank || !v.every((x) => Number.isInteger(x))) throw new Error(nm + "." + which + " must be an array of " + rank + " integers");
+      return v.slice();
+    };
+    const start = bound(src.start, "start", new Array(rank).fill(0)), end = bound(src.end, "end", shape);
+    for (let d = 0; d < rank; d++) {
+      if (start[d] < 0) throw new Error(nm + ".start[" + d + "] must be >= 0; got " + start[d]);
+      if (end[d] < 0) throw new Error(nm + ".end[" + d + "] must be >= 0; got " + end[d]);
+      if (start[d] > end[d]) throw new Error(nm + ": start[" + d + "] must be <= end[" + d + "]");
+      if (end[d] > shape[d]) throw new Error(nm + ".end[" + d + "] must be <= shape[" + d + "] (" + shape[d] + "); got " + end[d]);
+    }
+    if (start.every((s0) => s0 === 0) && end.every((e, d) => e === shape[d])) return null;
+    return { start, end };
+  };
+  return { read: stage(zeroPad.read, nm0 + ".read"), write: stage(zeroPad.write, nm0 + ".write") };
+}
+
 // Validates createPlan opts; returns { desc (native planCreate argument), meta }
 export function resolvePlanOptions(opts) {
   if (!isPlainObject(opts)) throw new Error("createPlan expects an options object");
@@ -264,12 +312,18 @@ export function resolvePlanOptions(opts) {
   const precision = dflt(opts.precision, "f32");
   assertOneOf(precision, ["f32", "f16-storage"], "precision");
   if (precision !== "f32") throw new Error('Unsupported: precision "f16-storage" is outside the MI355X hot path (f32 only)');
-  for (const key of ["ioView", "zeroPad"]) {
-    if (opts[key]) throw new Error("Unsupported: " + key + " is not built yet (SURVEY.md section 8f rank 2)");
+  const ioView = normalizeIoView(rank, shape, opts.ioView);
+  const zeroPad = normalizeZeroPad(rank, shape, opts.zeroPad);
+  if (type !== "c2c" && (ioView.input || ioView.output || zeroPad.read || zeroPad.write)) {
+    throw new Error("Unsupported: ioView / zeroPad on " + type + " are not built yet (c2c only; SURVEY.md section 8f rank 2)");
   }
   const inPlace = !!opts.inPlace;
-  const meta = { type, shape, rank, batch, inPlace };
+  const meta = { type, shape, rank, batch, inPlace, ioView, zeroPad };
   const desc = { type: TYPE_CODE[type], shape, batch, inPlace: inPlace ? 1 : 0, direction: 0, normalize: 0 };
+  if (ioView.input) desc.ioInput = ioView.input;
+  if (ioView.output) desc.ioOutput = Object.assign({}, ioView.output, { clearOutside: ioView.output.clearOutside ? 1 : 0 });
+  if (zeroPad.read) desc.zeroRead = zeroPad.read;
+  if (zeroPad.write) desc.zeroWrite = zeroPad.write;
 
   if (type === "fftconv") {
     const fc = opts.fftConv || {};
@@ -326,7 +380,9 @@ export function resolvePlanOptions(opts) {
   if (type === "c2r" && direction !== "inverse") throw new Error('c2r supports direction:"inverse" only');
   if (inPlace && type !== "c2c") throw new Error("inPlace=true is supported only on c2c");
   const packed = [Math.floor(shape[0] / 2) + 1].concat(shape.slice(1));
-  const sides = resolveLayoutSemantics(layout, rank, type === "c2r" ? packed : shape, type === "r2c" ? packed : shape);
+  const inShape = type === "c2r" ? packed : (ioView.input ? ioView.input.shape : shape);
+  const outShape = type === "r2c" ? packed : (ioView.output ? ioView.output.shape : shape);
+  const sides = resolveLayoutSemantics(layout, rank, inShape, outShape);
   desc.direction = DIRECTION_CODE[direction];
   desc.normalize = NORMALIZE_CODE[normalize];
   if (sides.input) desc.input = sides.input;

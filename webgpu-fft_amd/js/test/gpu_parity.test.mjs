@@ -201,6 +201,25 @@ test("fftconv BASELINE config 4 (README preset: shape=[256] batch=4, 64ch -> 128
   plan.destroy(); inBuf.destroy(); outBuf.destroy();
 });
 
+test("c2c ioView pad-in-read + zeroPad.write (docs/API.md examples)", async () => {
+  const dev = await ensureDevice();
+  const N = 16, V = 10;
+  const view = orc.randomComplexInterleaved(V, orc.mulberry32(99));
+  const logical = new Float32Array(2 * N);
+  logical.set(view, 2 * 3);                                   // placement "center": offset floor((16-10)/2) = 3
+  const want = orc.fftNdRef(logical, [N], "forward", "none");
+  for (let k = 0; k < N; k++) if (k < 2 || k >= 14) { want[2 * k] = 0; want[2 * k + 1] = 0; }   // zeroPad.write [2,14)
+  const inBuf = fft.uploadComplex(dev, view);
+  const outBuf = dev.createBuffer({ size: N * 8, usage: 0 });
+  const plan = fft.createPlan(dev, { type: "c2c", shape: [N], direction: "forward", ioView: { input: { shape: [V], placement: "center" } },
+    zeroPad: { write: { start: [2], end: [14] } } });
+  const enc = dev.createCommandEncoder();
+  plan.exec(enc, { input: inBuf, output: outBuf });
+  dev.queue.submit([enc.finish()]);
+  orc.assertCloseArray(await fft.downloadComplex(dev, outBuf, N), want, 3e-4, 3e-4, "ioView + zeroPad");
+  plan.destroy(); inBuf.destroy(); outBuf.destroy();
+});
+
 test("error behaviour: destroyed plan, missing output, in-place aliasing, offsets", async () => {
   const dev = await ensureDevice();
   const a = dev.createBuffer({ size: 1024, usage: 0 }), b = dev.createBuffer({ size: 1024, usage: 0 });

@@ -280,6 +280,30 @@ static void fill_side(napi_env env, napi_value parent, const char* name, mi355ff
   s->offset_elements = prop_i64(env, v, "offset", 0);
   s->batch_stride_elements = prop_i64(env, v, "batchStride", 0);
 }
+static napi_value get_obj_prop(napi_env env, napi_value parent, const char* name) {
+  napi_value v;
+  bool has = false;
+  napi_valuetype t;
+  if (napi_has_named_property(env, parent, name, &has) != napi_ok || !has) return NULL;
+  if (napi_get_named_property(env, parent, name, &v) != napi_ok) return NULL;
+  if (napi_typeof(env, v, &t) != napi_ok || t != napi_object) return NULL;
+  return v;
+}
+static void fill_view(napi_env env, napi_value parent, const char* name, mi355fft_io_view* dst) {
+  napi_value v = get_obj_prop(env, parent, name);
+  if (!v) return;
+  dst->enabled = 1;
+  dst->clear_outside = (int32_t)prop_i64(env, v, "clearOutside", 0);
+  prop_i64_array(env, v, "shape", dst->shape, MI355FFT_MAX_RANK);
+  prop_i64_array(env, v, "offset", dst->offset, MI355FFT_MAX_RANK);
+}
+static void fill_range(napi_env env, napi_value parent, const char* name, mi355fft_zero_range* dst) {
+  napi_value v = get_obj_prop(env, parent, name);
+  if (!v) return;
+  dst->enabled = 1;
+  prop_i64_array(env, v, "start", dst->start, MI355FFT_MAX_RANK);
+  prop_i64_array(env, v, "end", dst->end, MI355FFT_MAX_RANK);
+}
 static napi_value js_plan_create(napi_env env, napi_callback_info info) {
   napi_value a[2];
   if (!get_args(env, info, 2, a)) return NULL;
@@ -308,6 +332,10 @@ static napi_value js_plan_create(napi_env env, napi_callback_info info) {
   d.conv_output_layout = (int32_t)prop_i64(env, o, "convOutputLayout", 0);
   prop_i64_array(env, o, "convKernelShape", d.conv_kernel_shape, MI355FFT_MAX_RANK);
   d.conv_output_kernel_stride_elements = prop_i64(env, o, "convOutputKernelStrideElements", 0);
+  fill_view(env, o, "ioInput", &d.io_input);
+  fill_view(env, o, "ioOutput", &d.io_output);
+  fill_range(env, o, "zeroRead", &d.zero_read);
+  fill_range(env, o, "zeroWrite", &d.zero_write);
   mi355fft_plan* p = NULL;
   MI_CALL(env, mi355fft_plan_create((mi355fft_device*)get_ext(env, a[0]), &d, &p));
   return make_ext(env, p);

@@ -173,7 +173,8 @@ class Plan:
         self._resolved = resolved
         self.type = resolved["type"]
         self._desc = _abi.make_desc(resolved["type"], resolved["shape"], resolved["batch"], resolved["direction"], resolved["normalize"],
-                                    resolved["inPlace"], resolved["input_layout"], resolved["output_layout"], resolved.get("conv"))
+                                    resolved["inPlace"], resolved["input_layout"], resolved["output_layout"], resolved.get("conv"),
+                                    resolved.get("io_view"), resolved.get("zero_pad"))
         h = ctypes.c_void_p()
         _chk(lib().mi355fft_plan_create(device._h, ctypes.byref(self._desc), ctypes.byref(h)))
         self._h = h

@@ -29,6 +29,16 @@ class SideLayout(ctypes.Structure):
     ]
 
 
+class IoView(ctypes.Structure):
+    _fields_ = [("enabled", ctypes.c_int32), ("clear_outside", ctypes.c_int32), ("shape", ctypes.c_int64 * MAX_RANK),
+                ("offset", ctypes.c_int64 * MAX_RANK)]
+
+
+class ZeroRange(ctypes.Structure):
+    _fields_ = [("enabled", ctypes.c_int32), ("reserved", ctypes.c_int32), ("start", ctypes.c_int64 * MAX_RANK),
+                ("end", ctypes.c_int64 * MAX_RANK)]
+
+
 class PlanDesc(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_uint32),
@@ -47,6 +57,10 @@ class PlanDesc(ctypes.Structure):
         ("conv_output_layout", ctypes.c_int32),
         ("conv_kernel_shape", ctypes.c_int64 * MAX_RANK),
         ("conv_output_kernel_stride_elements", ctypes.c_int64),
+        ("io_input", IoView),
+        ("io_output", IoView),
+        ("zero_read", ZeroRange),
+        ("zero_write", ZeroRange),
     ]
 
 
@@ -78,8 +92,27 @@ def _fill_side(side, spec, rank):
     side.batch_stride_elements = int(spec.get("batch_stride", 0))
 
 
+def _fill_view(dst, spec, rank):
+    if not spec:
+        return
+    dst.enabled = 1
+    dst.clear_outside = 1 if spec.get("clearOutside") else 0
+    for i in range(rank):
+        dst.shape[i] = int(spec["shape"][i])
+        dst.offset[i] = int(spec["offset"][i])
+
+
+def _fill_range(dst, spec, rank):
+    if not spec:
+        return
+    dst.enabled = 1
+    for i in range(rank):
+        dst.start[i] = int(spec["start"][i])
+        dst.end[i] = int(spec["end"][i])
+
+
 def make_desc(type, shape, batch=1, direction="forward", normalize="none", in_place=False, input_layout=None, output_layout=None,
-              conv=None):
+              conv=None, io_view=None, zero_pad=None):
     """Build a PlanDesc from already-RESOLVED options (layout resolution lives in mi355fft.plans)."""
     d = PlanDesc()
     d.struct_size = ctypes.sizeof(PlanDesc)
@@ -105,6 +138,12 @@ def make_desc(type, shape, batch=1, direction="forward", normalize="none", in_pl
         d.conv_output_kernel_stride_elements = int(conv.get("outputKernelStrideElements", 0))
     else:
         d.conv_kernel_count = 1
+    if io_view:
+        _fill_view(d.io_input, io_view.get("input"), d.rank)
+        _fill_view(d.io_output, io_view.get("output"), d.rank)
+    if zero_pad:
+        _fill_range(d.zero_read, zero_pad.get("read"), d.rank)
+        _fill_range(d.zero_write, zero_pad.get("write"), d.rank)
     return d
 
 

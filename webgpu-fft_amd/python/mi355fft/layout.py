@@ -317,6 +317,69 @@ def _resolve_channel_policy(layout, policy, kernel_count, in_total, out_total):
     return merged, kstride
 
 
+def normalize_io_view(rank, logical_shape, io_view):
+    """runtime/ioview.js:7-37; a side that maps 1:1 onto the logical domain resolves to None"""
+    def one(v, kind):
+        if not v:
+            return None
+        shape = v.get("shape")
+        if not isinstance(shape, (list, tuple)) or len(shape) != rank or not all(_is_int(x) and x > 0 for x in shape):
+            raise ValueError(f"ioView.{kind}.shape must be an array of {rank} positive ints")
+        placement = v.get("placement", "start")
+        if placement not in ("start", "center"):
+            raise ValueError(f'ioView.{kind}.placement must be "start"|"center"')
+        offset = v.get("offset")
+        if offset is not None:
+            if not isinstance(offset, (list, tuple)) or len(offset) != rank or not all(_is_int(x) for x in offset):
+                raise ValueError(f"ioView.{kind}.offset must be an array of {rank} integers")
+            offset = list(offset)
+        elif placement == "center":
+            offset = [(logical_shape[d] - shape[d]) // 2 for d in range(rank)]
+        else:
+            offset = [0] * rank
+        if list(shape) == list(logical_shape) and all(o == 0 for o in offset):
+            return None
+        return {"shape": list(shape), "offset": offset, "clearOutside": bool(v.get("clearOutside")) if kind == "output" else False}
+    iv = io_view or {}
+    return {"input": one(iv.get("input"), "input"), "output": one(iv.get("output"), "output")}
+
+
+def normalize_zero_pad(rank, shape, zero_pad, name="zeroPad"):
+    """runtime/zero_pad.js:11-45; a stage covering the whole domain resolves to None"""
+    if not zero_pad:
+        return {"read": None, "write": None}
+    if not isinstance(zero_pad, dict):
+        raise ValueError(f"{name} must be an object with optional read/write stage configs")
+
+    def stage(st, nm):
+        if not st:
+            return None
+        if not isinstance(st, dict):
+            raise ValueError(f"{nm} must be an object with optional start/end arrays")
+        src = st["range"] if isinstance(st.get("range"), dict) else st
+
+        def bound(v, which, dflt):
+            if v is None:
+                return list(dflt)
+            if not isinstance(v, (list, tuple)) or len(v) != rank or not all(_is_int(x) for x in v):
+                raise ValueError(f"{nm}.{which} must be an array of {rank} integers")
+            return list(v)
+        start, end = bound(src.get("start"), "start", [0] * rank), bound(src.get("end"), "end", shape)
+        for d in range(rank):
+            if start[d] < 0:
+                raise ValueError(f"{nm}.start[{d}] must be >= 0; got {start[d]}")
+            if end[d] < 0:
+                raise ValueError(f"{nm}.end[{d}] must be >= 0; got {end[d]}")
+            if start[d] > end[d]:
+                raise ValueError(f"{nm}: start[{d}] must be <= end[{d}]")
+            if end[d] > shape[d]:
+                raise ValueError(f"{nm}.end[{d}] must be <= shape[{d}] ({shape[d]}); got {end[d]}")
+        if all(s0 == 0 for s0 in start) and all(e == shape[d] for d, e in enumerate(end)):
+            return None
+        return {"start": start, "end": end}
+    return {"read": stage(zero_pad.get("read"), f"{name}.read"), "write": stage(zero_pad.get("write"), f"{name}.write")}
+
+
 def resolve_plan_options(opts):
     """Validates createPlan opts and returns the resolved dict Plan/_abi.make_desc consume."""
     if not isinstance(opts, dict):
@@ -342,12 +405,14 @@ def resolve_plan_options(opts):
     _assert_one_of(precision, ("f32", "f16-storage"), "precision")
     if precision != "f32":
         raise NotImplementedError('precision "f16-storage" is outside the MI355X hot path (f32 only)')
-    for key in ("ioView", "zeroPad"):
-        if opts.get(key):
-            raise NotImplementedError(f"{key} is not built yet (SURVEY.md section 8f rank 2)")
+    io_view = normalize_io_view(rank, shape, opts.get("ioView"))
+    zero_pad = normalize_zero_pad(rank, shape, opts.get("zeroPad"))
+    if typ != "c2c" and (io_view["input"] or io_view["output"] or zero_pad["read"] or zero_pad["write"]):
+        raise NotImplementedError(f"ioView / zeroPad on {typ} are not built yet (c2c only; SURVEY.md section 8f rank 2)")
     in_place = bool(opts.get("inPlace", False))
     normalize = opts.get("normalize", "none")
-    out = {"type": typ, "shape": shape, "batch": batch, "inPlace": in_place, "normalize": normalize, "conv": None}
+    out = {"type": typ, "shape": shape, "batch": batch, "inPlace": in_place, "normalize": normalize, "conv": None,
+           "io_view": io_view, "zero_pad": zero_pad}
 
     if typ == "fftconv":
         fc = opts.get("fftConv") or {}
@@ -401,8 +466,8 @@ def resolve_plan_options(opts):
     if in_place and typ != "c2c":
         raise ValueError("inPlace=true is supported only on c2c")
     packed = [shape[0] // 2 + 1] + shape[1:]
-    in_shape = packed if typ == "c2r" else shape
-    out_shape = packed if typ == "r2c" else shape
+    in_shape = packed if typ == "c2r" else (io_view["input"]["shape"] if io_view["input"] else shape)
+    out_shape = packed if typ == "r2c" else (io_view["output"]["shape"] if io_view["output"] else shape)
     inp, outl = resolve_layout_semantics(layout, rank, in_shape, out_shape)
     out.update({"direction": direction, "input_layout": inp, "output_layout": outl})
     return out
