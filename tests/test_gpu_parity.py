@@ -382,6 +382,45 @@ def test_cfg3_full_size_properties(fft, dev, oracle):
     _full_size_properties(fft, dev, oracle, 1 << 20, 4096, 0x5EED0003)
 
 
+def test_cfg5_shard_full_size_properties(fft, dev, oracle):
+    """BASELINE config 5, one GPU's shard: r2c N=2^22 x 1024 transforms (16 GiB in, 16 GiB out): c2r(r2c(x)) = x, Parseval
+    for the packed spectrum, and sampled transforms against the oracle"""
+    n, batch, seed = 1 << 22, 1024, 0x5EED0005
+    p = n // 2 + 1
+    need = (2 * n * batch * 4) + p * batch * 8
+    if dev.info()["hbm_free"] < need + (4 << 30):
+        pytest.skip(f"needs {need >> 30} GiB of HBM")
+    x = dev.createBuffer({"size": n * batch * 4})
+    spec = dev.createBuffer({"size": p * batch * 8})
+    back = dev.createBuffer({"size": n * batch * 4})
+    dev.fillRandom(x, 0, n, batch, seed, 0)
+    fwd = fft.createPlan(dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
+    inv = fft.createPlan(dev, {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward"})
+    enc = dev.createCommandEncoder()
+    fwd.exec(enc, {"input": x, "output": spec})
+    inv.exec(enc, {"input": spec, "output": back})
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    e_in = dev.sumsq(x, 0, n * batch)
+    rt = dev.diffSumsq(back, 0, x, 0, 1.0, n * batch)
+    assert np.sqrt(rt / e_in) < 1e-5, f"round trip rel_l2={np.sqrt(rt / e_in):.3e}"
+    for t in (0, batch // 2, batch - 1):
+        xin = fft.downloadF32(dev, x, n, t * n * 4)
+        assert np.array_equal(xin, oracle.random_real(n, oracle.stream_seed(seed, t)))
+        got = fft.downloadF32(dev, spec, 2 * p, t * p * 8)
+        want = oracle.r2c_ref_packed(xin, n, "none", use_pow2=True)
+        l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
+        assert l2 <= TOL and mx <= TOL, f"transform {t}: rel_l2={l2:.3e} rel_max={mx:.3e}"
+        # Parseval on the packed half spectrum: sum|x|^2 = (|X0|^2 + |X_{N/2}|^2 + 2 sum_{0<k<N/2} |X_k|^2) / N
+        g = got.astype(np.float64).reshape(-1, 2)
+        pw = (g ** 2).sum(axis=1)
+        assert abs((pw[0] + pw[-1] + 2 * pw[1:-1].sum()) / n / float(np.sum(xin.astype(np.float64) ** 2)) - 1.0) < 1e-5
+    for pl in (fwd, inv):
+        pl.destroy()
+    for b in (x, spec, back):
+        b.destroy()
+
+
 def test_linearity_at_2p20(fft, dev, oracle):
     n, batch = 1 << 20, 4
     xs = [oracle.random_complex_batch(n, batch, 0x7100 + i).reshape(-1) for i in range(2)]

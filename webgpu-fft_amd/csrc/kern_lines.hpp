@@ -28,7 +28,27 @@
 #include "platform.hpp"
 #include "radix.hpp"
 
+// streamed-once global accesses of the line kernels: 0 = default cache policy, 1 = nontemporal loads + stores
+#ifndef MI355_NT_GLOBAL
+#define MI355_NT_GLOBAL 0
+#endif
+
 namespace mi355 {
+
+MI_DEV cf ld_stream(const cf* p) {
+#if MI355_NT_GLOBAL
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+MI_DEV void st_stream(cf* p, cf v) {
+#if MI355_NT_GLOBAL
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 // four-step twiddle e^{-2 pi i (line index in its group) * (element index) / Ntot}:
 //   TWID_FOURSTEP_OUT  multiplied into the last stage's outputs (LO table staged in LDS, HI from global)
@@ -157,7 +177,7 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
 #pragma unroll
       for (int q = 0; q < I::R; ++q) {
         const cf* pq = p + (unsigned)(b * C::TPL + q * (C::N / I::R)) * es;   // uniform
-        v[b * I::R + q] = cswap_if<C::SWAP_IN>(pq[voff]);
+        v[b * I::R + q] = cswap_if<C::SWAP_IN>(ld_stream(pq + voff));
       }
     }
   } else {
@@ -214,7 +234,7 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
         // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
         cf* pq = po + (unsigned)(b * C::TPL + q * I::NSP) * es;
         const unsigned voff = (unsigned)line * ls + (unsigned)u * es;
-        if (live) pq[voff] = cswap_if<C::SWAP_OUT>(r);
+        if (live) st_stream(pq + voff, cswap_if<C::SWAP_OUT>(r));
       } else {
         lds[lds_index<C>(line, oidx)] = w[q];
       }
