@@ -206,3 +206,38 @@ def test_support_kernels_match_oracle_prng(oracle):
     s = ctypes.c_double()
     emu.lib().emu_diff_sumsq(out.ctypes.data, None, 0.0, out.size, ctypes.byref(s))
     assert abs(s.value - float(np.sum(out.astype(np.float64) ** 2))) < 1e-9
+
+
+def test_r2c_c2r_whdcn_lanes(oracle):
+    """layout.whdcn on r2c / c2r: the real side and the packed side each resolve against their own physical shape
+    (docs/API.md "resolves per-side against the physical side shape"); only the addressed lane is read / written"""
+    from mi355fft.layout import resolve_plan_options
+    n, batch, channels, cidx = 32, 2, 3, 1
+    p = n // 2 + 1
+    x = oracle.random_real_batch(n, batch, 8800).reshape(-1)
+    phys_in = np.full(batch * channels * n, 9.0, np.float32)
+    for b in range(batch):
+        phys_in[b * channels * n + cidx * n: b * channels * n + (cidx + 1) * n] = x[b * n:(b + 1) * n]
+    r = resolve_plan_options({"type": "r2c", "shape": [n], "batch": batch, "direction": "forward",
+                              "layout": {"interleavedComplex": True, "whdcn": {"channels": channels, "channelIndex": cidx}}})
+    assert r["input_layout"] == {"strides": [1], "offset": cidx * n, "batch_stride": channels * n}
+    assert r["output_layout"] == {"strides": [1], "offset": cidx * p, "batch_stride": channels * p}
+    desc = _abi.make_desc("r2c", [n], batch, "forward", "none", input_layout=r["input_layout"], output_layout=r["output_layout"])
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), batch * channels * p)
+    got, route, _ = emu.run_plan(desc, phys_in, sentinel.size, out_init=sentinel)
+    assert "gather" in route and "scatter" in route
+    want = sentinel.copy()
+    for b in range(batch):
+        base = 2 * (b * channels * p + cidx * p)
+        want[base:base + 2 * p] = oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none")
+    check(got, want, "r2c whdcn lanes")
+    # c2r back out of the lanes into real lanes
+    r = resolve_plan_options({"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward",
+                              "layout": {"interleavedComplex": True, "whdcn": {"channels": channels, "channelIndex": cidx}}})
+    desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward", input_layout=r["input_layout"], output_layout=r["output_layout"])
+    rs = np.full(batch * channels * n, -3.0, np.float32)
+    back, route, _ = emu.run_plan(desc, want, rs.size, out_init=rs)
+    wantr = rs.copy()
+    for b in range(batch):
+        wantr[b * channels * n + cidx * n: b * channels * n + (cidx + 1) * n] = x[b * n:(b + 1) * n]
+    assert float(np.max(np.abs(back - wantr))) < 2e-6

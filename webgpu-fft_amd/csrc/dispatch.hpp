@@ -137,12 +137,13 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) 
     case ST_GATHER:
     case ST_SCATTER: {
       StridedArgs a{};
-      a.src = (const cf*)ptr[0]; a.dst = (cf*)ptr[1];
+      a.src = ptr[0]; a.dst = ptr[1];
       a.total = s.i[0]; a.per = s.i[1]; a.rank = (int)s.i[2];
       a.phys_offset = s.i[3]; a.phys_batch_stride = s.i[4]; a.dense_offset = s.i[5]; a.dense_batch_stride = s.i[6];
       for (int d = 0; d < 8; ++d) { a.shape[d] = s.shape[d] ? s.shape[d] : 1; a.phys_stride[d] = s.sa[d]; a.dense_stride[d] = s.sb[d]; }
-      if (s.kind == ST_GATHER) l.launch(strided_copy_kernel<true>, s.grid, 256u, 0u, a);
-      else l.launch(strided_copy_kernel<false>, s.grid, 256u, 0u, a);
+      const bool real = s.i[7] != 0;     // element type: 0 complex, 1 real (r2c input / c2r output sides)
+      if (s.kind == ST_GATHER) { if (real) l.launch(strided_copy_kernel<true, float>, s.grid, 256u, 0u, a); else l.launch(strided_copy_kernel<true, cf>, s.grid, 256u, 0u, a); }
+      else { if (real) l.launch(strided_copy_kernel<false, float>, s.grid, 256u, 0u, a); else l.launch(strided_copy_kernel<false, cf>, s.grid, 256u, 0u, a); }
       return true;
     }
     case ST_FFTCONV_FUSED: {

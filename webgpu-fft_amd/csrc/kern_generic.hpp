@@ -73,7 +73,6 @@ static __global__ void __launch_bounds__(256) scale_kernel(float* data, long lon
 // r2c, even N, H = N/2.  Z[b][k] (k < H) = FFT_H of z[n] = x[2n] + i x[2n+1]; writes the packed spectrum
 // X[b][k], k = 0..H (H+1 bins per line, reference packing docs/API.md "R2C/C2R packing"):
 //   X[k] = (Z[k] + conj(Z[H-k]))/2 - (i/2) e^{-2 pi i k/N} (Z[k] - conj(Z[H-k])),  Z[H] := Z[0]
-// tw[k] = e^{-2 pi i k/N}, k <= H/2 suffices but the table holds k < H+1.
 // The root e^{-2 pi i k/N} is formed as HI[k >> shift] * LO[k & mask] from two small cache-resident tables, not
 // read from an (N/2+1)-entry table: at N = 2^22 that table would add 4 B per complex point of fabric traffic.
 struct R2cPostArgs {
@@ -83,7 +82,7 @@ struct R2cPostArgs {
   float scale;
   int shift; unsigned mask;
 };
-// Work item = (line b, chunk of 256 consecutive k): the divisions are wave-uniform (scalar), lanes walk k.
+// Work item = (line b, chunk of 1024 consecutive k, 4 per lane): the divisions are wave-uniform (scalar), lanes walk k.
 // One lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2, so every Z is read once:
 //   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
 static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
@@ -249,7 +248,7 @@ static __global__ void __launch_bounds__(256) pointwise_mul_kernel(const cf* dat
 // `sub` selects a window of the dense side: dense coords = coord + sub_offset inside dense_shape
 // (embedding a small kernel / input into a zero-padded FFT domain, or cropping a result).
 struct StridedArgs {
-  const cf* src; cf* dst;
+  const void* src; void* dst;     // elements are complex (cf) or real (float): strided_copy_kernel<GATHER, ELEM>
   long long total;                 // batch * prod(shape)
   long long per;                   // prod(shape)  (shape = extent of the moved region)
   int rank;
@@ -259,8 +258,10 @@ struct StridedArgs {
   long long dense_stride[8];       // strides of the dense side's full domain
   long long dense_offset, dense_batch_stride;
 };
-template <bool GATHER>
+template <bool GATHER, class ELEM = cf>
 static __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedArgs a) {
+  const ELEM* src = static_cast<const ELEM*>(a.src);
+  ELEM* dst = static_cast<ELEM*>(a.dst);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
     const long long b = g / a.per;
     long long rem = g - b * a.per;
@@ -272,7 +273,7 @@ static __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedA
       p += c * a.phys_stride[i];
       d += c * a.dense_stride[i];
     }
-    if constexpr (GATHER) a.dst[d] = a.src[p]; else a.dst[p] = a.src[d];
+    if constexpr (GATHER) dst[d] = src[p]; else dst[p] = src[d];
   }
 }
 

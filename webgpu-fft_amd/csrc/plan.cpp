@@ -405,8 +405,10 @@ struct Builder {
   }
 
   void emit_strided(bool gather, PtrRef phys, PtrRef dense, const mi355fft_side_layout& lay, const int64_t* shape, int rank, int64_t batch,
-                    const int64_t* dense_shape, const int64_t* dense_sub_offset, int64_t dense_batch_stride, int64_t extra_phys_offset) {
+                    const int64_t* dense_shape, const int64_t* dense_sub_offset, int64_t dense_batch_stride, int64_t extra_phys_offset,
+                    bool real_elements = false) {
     Step& st = push(gather ? ST_GATHER : ST_SCATTER);
+    st.i[7] = real_elements ? 1 : 0;
     st.p[0] = gather ? phys : dense;
     st.p[1] = gather ? dense : phys;
     const int64_t per = prodv(shape, rank);
@@ -588,14 +590,26 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (int rv = reject_views(d, "r2c", err)) return rv;
   if (d.direction != MI355FFT_FORWARD) { err = "r2c supports direction:\"forward\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
-  if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on r2c are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
   const int64_t N = d.shape[0], P = N / 2 + 1;
   if (N < 2) { err = "r2c requires shape[0] >= 2"; return MI355FFT_ERR_INVALID; }
   const int64_t n = prodv(d.shape, d.rank), lines = d.batch * (n / N);
   const float scale = (float)scale_factor(d.normalize, false, (double)n);
+  int64_t pshape[MI355FFT_MAX_RANK];
+  for (int i = 0; i < d.rank; ++i) pshape[i] = d.shape[i];
+  pshape[0] = P;
+  const int64_t pn = prodv(pshape, d.rank);
   PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
-  b.ir.in_bytes = (uint64_t)n * d.batch * 4;
-  b.ir.out_bytes = (uint64_t)lines * P * 8;
+  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, d.shape, d.rank, d.batch, 0) * 4 : (uint64_t)n * d.batch * 4;
+  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, pshape, d.rank, d.batch, 0) * 8 : (uint64_t)lines * P * 8;
+  // strided sides (layout.strides / layout.whdcn): real gather in front, complex scatter of the packed spectrum behind
+  const PtrRef user_out = out;
+  if (d.input.strided) {
+    const PtrRef dense_in = b.alloc_work((uint64_t)n * d.batch * 4);
+    b.emit_strided(true, in, dense_in, d.input, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0, true);
+    in = dense_in;
+    b.ir.route += "gather ";
+  }
+  if (d.output.strided) out = b.alloc_work((uint64_t)pn * d.batch * 8);
   if (N % 2 == 0) {
     const int64_t H = N / 2;
     PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
@@ -620,10 +634,12 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     b.ir.route += "r2c-full ";
   }
   if (d.rank > 1) {
-    int64_t ps[MI355FFT_MAX_RANK];
-    for (int i = 0; i < d.rank; ++i) ps[i] = d.shape[i];
-    ps[0] = P;
-    return b.emit_nd(out, out, ps, d.rank, d.batch, false, 1.0f, err, 1);
+    const int rc = b.emit_nd(out, out, pshape, d.rank, d.batch, false, 1.0f, err, 1);
+    if (rc) return rc;
+  }
+  if (d.output.strided) {
+    b.emit_strided(false, user_out, out, d.output, pshape, d.rank, d.batch, pshape, nullptr, pn, 0);
+    b.ir.route += "scatter ";
   }
   return MI355FFT_OK;
 }
@@ -632,14 +648,25 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (int rv = reject_views(d, "c2r", err)) return rv;
   if (d.direction != MI355FFT_INVERSE) { err = "c2r supports direction:\"inverse\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
-  if (d.input.strided || d.output.strided) { err = "Unsupported: strided layouts on c2r are not built yet"; return MI355FFT_ERR_UNSUPPORTED; }
   const int64_t N = d.shape[0], P = N / 2 + 1;
   if (N < 2) { err = "c2r requires shape[0] >= 2"; return MI355FFT_ERR_INVALID; }
   const int64_t n = prodv(d.shape, d.rank), lines = d.batch * (n / N);
   const float scale = (float)scale_factor(d.normalize, true, (double)n);
+  int64_t pshape[MI355FFT_MAX_RANK];
+  for (int i = 0; i < d.rank; ++i) pshape[i] = d.shape[i];
+  pshape[0] = P;
+  const int64_t pn = prodv(pshape, d.rank);
   PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
-  b.ir.in_bytes = (uint64_t)lines * P * 8;
-  b.ir.out_bytes = (uint64_t)n * d.batch * 4;
+  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, pshape, d.rank, d.batch, 0) * 8 : (uint64_t)lines * P * 8;
+  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, d.shape, d.rank, d.batch, 0) * 4 : (uint64_t)n * d.batch * 4;
+  const PtrRef user_out = out;
+  if (d.input.strided) {
+    const PtrRef dense_in = b.alloc_work((uint64_t)pn * d.batch * 8);
+    b.emit_strided(true, in, dense_in, d.input, pshape, d.rank, d.batch, pshape, nullptr, pn, 0);
+    in = dense_in;
+    b.ir.route += "gather ";
+  }
+  if (d.output.strided) out = b.alloc_work((uint64_t)n * d.batch * 4);
   PtrRef packed = in;
   if (d.rank > 1) {
     // inverse c2c over axes 1.. of the packed spectrum; the caller's input is not modified
@@ -675,6 +702,10 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     r.p[0] = full; r.p[1] = out; r.i[0] = lines * N; r.f[0] = scale;
     r.grid = b.generic_grid(lines * N);
     b.ir.route += "c2r-full ";
+  }
+  if (d.output.strided) {
+    b.emit_strided(false, user_out, out, d.output, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0, true);
+    b.ir.route += "scatter ";
   }
   return MI355FFT_OK;
 }
