@@ -21,8 +21,10 @@
 namespace emu {
 thread_local dim3_t t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local char* t_smem = nullptr;
+unsigned g_xcds = 2;
 static thread_local pthread_barrier_t* t_barrier = nullptr;
 void sync_threads() { pthread_barrier_wait(t_barrier); }
+void yield_thread() { std::this_thread::yield(); }
 }  // namespace emu
 
 namespace {
@@ -57,6 +59,30 @@ struct EmuLauncher {
     pthread_barrier_destroy(&bar);
   }
   void copy(void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
+
+  unsigned sticky = 0;
+  unsigned* sticky_error_word() { return &sticky; }
+  // kernels whose workgroups synchronise with each other (kern_xcd.hpp): every block gets its own threads,
+  // barrier and shared memory, and all blocks run at the same time
+  template <class... P, class... A>
+  void launch_concurrent(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args) {
+    const size_t bytes = std::max<size_t>(smem, 64 * 1024) + 64;
+    std::vector<std::vector<char>> shared(grid, std::vector<char>(bytes));
+    std::vector<pthread_barrier_t> bars(grid);
+    for (auto& b : bars) pthread_barrier_init(&b, nullptr, block);
+    std::vector<std::thread> th;
+    th.reserve((size_t)grid * block);
+    for (unsigned b = 0; b < grid; ++b)
+      for (unsigned t = 0; t < block; ++t)
+        th.emplace_back([&, b, t] {
+          emu::t_barrier = &bars[b];
+          emu::t_smem = shared[b].data() + (64 - (reinterpret_cast<uintptr_t>(shared[b].data()) & 63)) % 64;
+          emu::t_blockDim.x = block; emu::t_gridDim.x = grid; emu::t_threadIdx.x = t; emu::t_blockIdx.x = b;
+          kernel(args...);
+        });
+    for (auto& t : th) t.join();
+    for (auto& b : bars) pthread_barrier_destroy(&b);
+  }
 };
 
 }  // namespace
@@ -100,7 +126,9 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   PlannerOptions opt;
   opt.force_generic = force_generic;
   if (chunk_bytes) opt.chunk_bytes = chunk_bytes;
-  opt.compute_units = 2;
+  opt.compute_units = std::getenv("MI355_EMU_CUS") ? std::atoi(std::getenv("MI355_EMU_CUS")) : 2;
+  if (const char* e = std::getenv("MI355_EMU_XCD_FUSED")) opt.xcd_fused = std::atoi(e); else opt.xcd_fused = 0;
+  emu::g_xcds = std::getenv("MI355_EMU_XCDS") ? (unsigned)std::atoi(std::getenv("MI355_EMU_XCDS")) : 2u;
   PlanIR ir;
   std::string e;
   const int rc = build_plan(*desc, opt, ir, e);
@@ -126,8 +154,10 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   for (const Step& s : ir.steps) {
     void* ptr[5];
     for (int i = 0; i < 5; ++i) ptr[i] = s.p[i].buf == BUF_NONE ? nullptr : (char*)base[s.p[i].buf] + s.p[i].off;
-    if (!dispatch_step(s, ptr, l, lines_fn)) { std::snprintf(err, err_bytes, "no kernel for step kind %d variant %d", (int)s.kind, s.variant); return 103; }
+    auto xcd_fn = [&](int id, const XcdFusedArgs& a, unsigned grid) { return launch_xcd_fused(id, a, grid, l); };
+    if (!dispatch_step(s, ptr, l, lines_fn, xcd_fn)) { std::snprintf(err, err_bytes, "no kernel for step kind %d variant %d", (int)s.kind, s.variant); return 103; }
   }
+  if (l.sticky) { std::snprintf(err, err_bytes, "XCD-fused kernel gave up waiting (sticky=%u)", l.sticky); return 104; }
   return 0;
 }
 

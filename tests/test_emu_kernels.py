@@ -241,3 +241,22 @@ def test_r2c_c2r_whdcn_lanes(oracle):
     for b in range(batch):
         wantr[b * channels * n + cidx * n: b * channels * n + (cidx + 1) * n] = x[b * n:(b + 1) * n]
     assert float(np.max(np.abs(back - wantr))) < 2e-6
+
+
+@pytest.mark.parametrize("cus,xcds", [(2, 2), (4, 2), (6, 3), (3, 1)])
+def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds):
+    """both passes in one persistent launch; workgroups grouped by (emulated) XCC id synchronise through global
+    counters: blocks run concurrently under emulation.  N = 64 x 64 is the test instance of the kernel template."""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    n, batch = 4096, 5
+    x = oracle.random_complex_batch(n, batch, 0xF00D + cus).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith("xcd-fused[N=64x64]") and launches == 2
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused {direction} cus={cus} xcds={xcds}")
+    desc = _abi.make_desc("c2c", [n], batch, "forward", "unitary", in_place=True)
+    got, route, _ = emu.run_plan(desc, x, x.size)
+    check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")

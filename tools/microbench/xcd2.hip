@@ -107,6 +107,57 @@ __global__ void __launch_bounds__(512) k_proto(const cf* x, cf* out, cf* hbuf, i
   if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+// Prototype 2: per-XCD fused two-pass.  Phase A: 2 column tiles per workgroup, x -> W slot (pass-A pattern); XCD barrier;
+// phase B: 2 row tiles per workgroup, W slot (rows) -> out (transposed 128-B segments); XCD barrier.  W slot = 8 MiB per XCD,
+// reused every transform: whatever stays in the 4 MiB L2 / the Infinity Cache never touches HBM.
+template <bool REVERSE_B>
+__global__ void __launch_bounds__(512) k_fused2(const cf* x, cf* out, cf* wbuf, int transforms, Ctl* c) {
+  extern __shared__ char pad[];
+  __shared__ unsigned s_x, s_r, s_ok;
+  if (threadIdx.x == 0) {
+    s_x = xcc_id() & 7;
+    s_r = __hip_atomic_fetch_add(&c->reg_xcd[s_x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&c->reg_total, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = 0;
+    for (int it = 0; it < 2000000; ++it) { if (__hip_atomic_load(&c->reg_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) { s_ok = 1; break; } __builtin_amdgcn_s_sleep(4); }
+    if (__hip_atomic_load(&c->reg_xcd[s_x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 32) s_ok = 0;
+    if (!s_ok) atomicAdd(&c->err, 1u);
+  }
+  __syncthreads();
+  if (!s_ok) return;
+  const unsigned xcc = s_x, r = s_r;
+  const int t = threadIdx.x, cc = t % 16, u = t / 16;
+  const int row = t / 32, j = t % 32;
+  cf* W = wbuf + (size_t)xcc * 1048576;
+  unsigned bar = 0;
+  for (int n = 0; n < transforms; ++n) {
+    const size_t tr = (size_t)(n * 8 + xcc);
+    const cf* xt = x + tr * 1048576;
+    cf* ot = out + tr * 1048576;
+    for (int half = 0; half < 2; ++half) {
+      cf a[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a[q] = xt[(unsigned)((u + 32 * q) * 1024 + 32 * r + 16 * half + cc)];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) a[q] = a[q] * 1.0001f + a[(q + 1) & 31];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) W[(unsigned)((u + 32 * q) * 1024 + 32 * r + 16 * half + cc)] = a[q];
+    }
+    if (!xcd_barrier(c, xcc, (++bar) * 32)) return;
+    for (int half = 0; half < 2; ++half) {
+      const unsigned rr = REVERSE_B ? (31 - r) : r;      // which row tiles this workgroup takes in phase B
+      cf b[32];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) b[q] = W[(unsigned)((32 * rr + 16 * half + row) * 1024 + j + 32 * q)];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) b[q] = b[q] * 0.5f + b[(q + 3) & 31];
+#pragma unroll
+      for (int q = 0; q < 32; ++q) ot[(unsigned)((u + 32 * q) * 1024 + 32 * rr + 16 * half + cc)] = b[q];
+    }
+    if (!xcd_barrier(c, xcc, (++bar) * 32)) return;
+  }
+}
+
 int main() {
   const unsigned LDS = 100 * 1024;
   const int TR = 64;                       // transforms per XCD
@@ -135,6 +186,24 @@ int main() {
   run(1, "HBM part only (16 B/pt, no exchange)");
   run(2, "exchange only (2 rounds through L2, 4 barriers)");
   run(0, "full skeleton");
+  {
+    cf* w; CK(hipMalloc(&w, (size_t)8 * 1048576 * 8));
+    for (int rev = 0; rev < 2; ++rev) {
+      float best = 1e30f; unsigned err = 0;
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemset(c, 0, sizeof(Ctl)));
+        CK(hipEventRecord(e0));
+        if (rev) { CK(hipFuncSetAttribute((const void*)k_fused2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); hipLaunchKernelGGL(k_fused2<true>, dim3(256), dim3(512), LDS, 0, x, out, w, TR, c); }
+        else { CK(hipFuncSetAttribute((const void*)k_fused2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); hipLaunchKernelGGL(k_fused2<false>, dim3(256), dim3(512), LDS, 0, x, out, w, TR, c); }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        Ctl hc; CK(hipMemcpy(&hc, c, sizeof(Ctl), hipMemcpyDeviceToHost)); err += hc.err;
+      }
+      const double per_tr = best * 1e3 / (TR * 8);
+      printf("%-46s %8.3f ms for %d transforms: %6.3f us/transform -> %6.1f GPoints/s (N=2^20)  err=%u\n", rev ? "fused two-pass per XCD via W slot (B reversed)" : "fused two-pass per XCD via 8 MiB W slot", best, TR * 8, per_tr,
+             1048576.0 / per_tr / 1e3, err);
+    }
+  }
   run(4, "HBM part only, nontemporal loads/stores");
   run(3, "full skeleton, nontemporal HBM loads/stores");
   return 0;

@@ -46,6 +46,8 @@ struct mi355fft_device {
   hipStream_t capture_stream = nullptr;
   int compute_units = 256;
   std::string arch;
+  unsigned* sticky = nullptr;     // device word raised by kernels whose bounded waits timed out (kern_xcd.hpp)
+  bool sticky_armed = false;      // a kernel that can raise it has been submitted since the last check
 };
 struct mi355fft_buffer {
   mi355fft_device* dev = nullptr;
@@ -88,7 +90,8 @@ bool lines_dispatch(int family, int id, const LineArgs& a, unsigned grid, HipLau
 
 int replay(const std::vector<RecordedOp>& ops, HipLauncher& l) {
   for (const RecordedOp& op : ops) {
-    const bool ok = dispatch_step(op.step, op.ptr, l, [&](int fam, int id, const LineArgs& a, unsigned grid) { return lines_dispatch(fam, id, a, grid, l); });
+    const bool ok = dispatch_step(op.step, op.ptr, l, [&](int fam, int id, const LineArgs& a, unsigned grid) { return lines_dispatch(fam, id, a, grid, l); },
+                                  [&](int id, const XcdFusedArgs& a, unsigned grid) { return launch_xcd_fused(id, a, grid, l); });
     if (!ok) return fail(MI355FFT_ERR_UNSUPPORTED, "no kernel instance for step kind %d variant %d", (int)op.step.kind, op.step.variant);
     if (l.status != hipSuccess) return fail(MI355FFT_ERR_HIP, "HIP error %d (%s) launching step kind %d", (int)l.status, hipGetErrorString(l.status), (int)op.step.kind);
   }
@@ -133,6 +136,8 @@ MI_API int mi355fft_device_open(int ordinal, mi355fft_device** out) {
   d->arch = prop.gcnArchName;
   HIP_TRY(hipStreamCreate(&d->stream));
   HIP_TRY(hipStreamCreateWithFlags(&d->capture_stream, hipStreamNonBlocking));
+  HIP_TRY(hipMalloc((void**)&d->sticky, 64));
+  HIP_TRY(hipMemset(d->sticky, 0, 64));
   *out = d.release();
   return MI355FFT_OK;
 }
@@ -143,6 +148,7 @@ MI_API int mi355fft_device_close(mi355fft_device* dev) {
   (void)hipStreamSynchronize(dev->stream);
   (void)hipStreamDestroy(dev->stream);
   (void)hipStreamDestroy(dev->capture_stream);
+  if (dev->sticky) (void)hipFree(dev->sticky);
   delete dev;
   return MI355FFT_OK;
 }
@@ -241,9 +247,11 @@ MI_API int mi355fft_plan_create(mi355fft_device* dev, const mi355fft_plan_desc* 
   // raise dynamic-LDS limits now: hipFuncSetAttribute is not legal inside a later stream capture
   {
     HipLauncher l;
+    l.sticky = dev->sticky;
     l.prepare_only = true;
+    for (const Step& s : p->ir.steps) if (s.kind == ST_XCD_FUSED) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); op.ptr[4] = p->table; (void)op; }
     std::vector<RecordedOp> probe;
-    for (const Step& s : p->ir.steps) if (s.kind == ST_LINES) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
+    for (const Step& s : p->ir.steps) if (s.kind == ST_LINES || s.kind == ST_XCD_FUSED) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
     const int prc = replay(probe, l);
     if (prc) { (void)hipFree(p->table); return prc; }
   }
@@ -382,6 +390,7 @@ MI_API int mi355fft_encoder_finish(mi355fft_encoder* enc, int use_graph, mi355ff
     if (e != hipSuccess) { destroy_commands(c); return fail(MI355FFT_ERR_HIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(e)); }
     HipLauncher l;
     l.stream = dev->capture_stream;
+    l.sticky = dev->sticky;
     const int rc = replay(c->ops, l);
     e = hipStreamEndCapture(dev->capture_stream, &c->graph);
     if (rc) { destroy_commands(c); return rc; }
@@ -397,9 +406,11 @@ MI_API int mi355fft_queue_submit(mi355fft_device* dev, mi355fft_commands* cmds) 
   if (!dev || !cmds) return fail(MI355FFT_ERR_INVALID, "submit: device and command list are required");
   if (cmds->dev != dev) return fail(MI355FFT_ERR_INVALID, "command list belongs to a different device");
   HIP_TRY(hipSetDevice(dev->ordinal));
+  for (const RecordedOp& op : cmds->ops) if (op.step.kind == ST_XCD_FUSED) dev->sticky_armed = true;
   if (cmds->exec) { HIP_TRY(hipGraphLaunch(cmds->exec, dev->stream)); return MI355FFT_OK; }
   HipLauncher l;
   l.stream = dev->stream;
+  l.sticky = dev->sticky;
   return replay(cmds->ops, l);
 }
 
@@ -415,6 +426,16 @@ MI_API int mi355fft_queue_wait(mi355fft_device* dev) {
   if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
   HIP_TRY(hipSetDevice(dev->ordinal));
   HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (dev->sticky_armed) {
+    dev->sticky_armed = false;
+    unsigned word = 0;
+    HIP_TRY(hipMemcpy(&word, dev->sticky, sizeof word, hipMemcpyDeviceToHost));
+    if (word) {
+      (void)hipMemset(dev->sticky, 0, sizeof word);
+      return fail(MI355FFT_ERR_HIP, "XCD-fused FFT kernel gave up waiting (%s%s): its workgroups were not all co-resident; results of that submit are "
+                  "invalid.  Set MI355FFT_XCD_FUSED=0 to use the two-kernel route.", (word & 1u) ? "registration " : "", (word & 2u) ? "barrier" : "");
+    }
+  }
   return MI355FFT_OK;
 }
 

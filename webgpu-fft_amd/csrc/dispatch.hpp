@@ -11,6 +11,7 @@
 #include "kern_fftconv.hpp"
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
+#include "kern_xcd.hpp"
 #include "plan.hpp"
 
 namespace mi355 {
@@ -70,6 +71,30 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
   return false;
 }
 
+// XCD-fused four-step kernels live in their own translation unit in the product build (lines_fam_xcd.hip)
+template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
+  int cur = 0;
+#define X(N1, A0, A1, A2, N2, B0, B1, B2)                                                          \
+  if (id == cur++) {                                                                              \
+    using CA = LineCfg<N1, A0, A1, A2, 16, true, true, false, false, 0>;                          \
+    using CB = LineCfg<N2, B0, B1, B2, 16, false, true, false, false, 0>;                         \
+    using F = XcdFusedCfg<CA, CB>;                                                                \
+    l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
+    return true;                                                                                  \
+  }                                                                                               \
+  if (id == cur++) {                                                                              \
+    using CA = LineCfg<N1, A0, A1, A2, 16, true, true, true, false, 0>;                           \
+    using CB = LineCfg<N2, B0, B1, B2, 16, false, true, false, true, 0>;                          \
+    using F = XcdFusedCfg<CA, CB>;                                                                \
+    l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
+    return true;                                                                                  \
+  }
+  MI355_XCD_KERNEL_LIST(X)
+#undef X
+  (void)cur;
+  return false;
+}
+
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
   switch (radix) {
 #define MI_STAGE_CASE(R) case R: l.launch(stockham_stage_kernel<R>, grid, 256u, 0u, a); return true;
@@ -82,9 +107,20 @@ template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned gri
 
 // LinesFn: bool(int family, int id, const LineArgs&, unsigned grid) — supplied by the caller because the
 // per-family instantiations live in different translation units in the product build.
-template <class L, class LinesFn>
-bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn) {
+template <class L, class LinesFn, class XcdFn>
+bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, XcdFn&& xcd_fn) {
   switch (s.kind) {
+    case ST_XCD_FUSED: {
+      XcdFusedArgs a{};
+      a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.wslots = (cf*)ptr[2]; a.ctl = (XcdCtl*)ptr[3];
+      const char* tb = (const char*)ptr[4];
+      a.tw_a = (const cf*)(tb + s.i[4]); a.tw_b = (const cf*)(tb + s.i[5]); a.tw_lo = (const cf*)(tb + s.i[6]); a.tw_hi = (const cf*)(tb + s.i[7]);
+      a.num_transforms = s.i[0]; a.N = s.i[1]; a.fs_shift = (int)s.i[2]; a.fs_lo_mask = (unsigned)s.i[3];
+      a.scale = s.f[0];
+      a.sticky_error = l.sticky_error_word();
+      a.spin_limit = 4000000u;
+      return xcd_fn(s.variant, a, s.grid);
+    }
     case ST_LINES: {
       LineArgs a{};
       a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2]; a.tw_lo = (const cf*)ptr[3]; a.tw_hi = (const cf*)ptr[4];

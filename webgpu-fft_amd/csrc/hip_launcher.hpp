@@ -14,6 +14,14 @@ struct HipLauncher {
   hipStream_t stream = nullptr;
   bool prepare_only = false;   // only raise dynamic-LDS limits (must happen outside stream capture)
   hipError_t status = hipSuccess;
+  unsigned* sticky = nullptr;  // device-wide error word raised by kernels with bounded waits (kern_xcd.hpp)
+  unsigned* sticky_error_word() const { return sticky; }
+  // kernels whose workgroups synchronise with each other: same launch on hardware (the grid is sized so that every
+  // workgroup is resident: one per CU); the emulation needs its blocks to run concurrently
+  template <class... P, class... A>
+  void launch_concurrent(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args) {
+    launch(kernel, grid, block, smem, static_cast<A&&>(args)...);
+  }
 
   static void raise_lds_limit(const void* fn, unsigned smem, hipError_t& status) {
     static std::mutex mu;
@@ -47,5 +55,6 @@ extern template bool launch_lines_family<FAM_ROW_1K, HipLauncher>(int, const Lin
 extern template bool launch_lines_family<FAM_ROW_BIG, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 extern template bool launch_lines_family<FAM_PASS_A, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 extern template bool launch_lines_family<FAM_PASS_B, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
+extern template bool launch_xcd_fused<HipLauncher>(int, const XcdFusedArgs&, unsigned, HipLauncher&);
 
 }  // namespace mi355

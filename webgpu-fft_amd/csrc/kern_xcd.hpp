@@ -1,0 +1,196 @@
+// kern_xcd.hpp — XCD-fused four-step: both passes of an N = N1*N2 transform in ONE persistent launch, the 32
+// workgroups that share an XCD (one per CU) working on one transform at a time.
+//
+// Why (profiles/r01_xcd_fused_two_pass_prototype.log): the two-kernel route moves every point over
+// the fabric four times (32 B/point) and both passes already run at the speed of a copy with their access pattern.
+// Here pass A writes its 8 MiB intermediate into a per-XCD workspace slot that is re-used for every transform and pass B
+// of the SAME XCD reads it back a few microseconds later: whatever is still in that XCD's 4 MiB L2 (or the Infinity Cache)
+// never crosses the fabric twice.  The data-movement skeleton measured 5.6 us per 2^20-point transform against 6.6 for the
+// two-kernel route.
+//
+// Structure per launch (grid = one workgroup per CU, LDS-limited):
+//   registration: every workgroup reads its XCC id, takes a rank inside that XCD and waits (bounded) until all
+//                 gridDim.x workgroups have registered; groups = the XCDs that received workgroups.  Nothing assumes a
+//                 placement: a group is BY CONSTRUCTION the set of workgroups behind one L2.
+//   per transform t (group g takes t = g, g+G, ...):
+//     phase A  column tiles r, r+s, ... of x_t -> W[xcc]      (kern_lines.hpp PASS_A stages)
+//     XCD barrier
+//     phase B  row tiles r, r+s, ... of W[xcc] -> out_t       (PASS_B stages, four-step roots generated per tile)
+//     XCD barrier (W[xcc] may be overwritten)
+// Hand-off protocol (same-XCD by construction, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"): producers'
+// stores are complete in the shared L2 after `s_waitcnt vmcnt(0)`; one lane per workgroup adds to the group's monotonic
+// counter and polls it with relaxed agent-scope loads; every consumer workgroup then invalidates its CU's L1 with an
+// agent-scope acquire before reading.  No L2 write-back is needed because producer and consumer share that L2.
+// Every spin is bounded: on a timeout the workgroup raises a sticky error word and returns (queue_wait reports it).
+#pragma once
+#include "kern_lines.hpp"
+
+namespace mi355 {
+
+struct XcdCtl {                  // zeroed by a memset step before every launch
+  unsigned reg_total;
+  unsigned reg_xcd[16];
+  unsigned bar[16][16];          // one 64-byte line per XCC id
+};
+
+struct XcdFusedArgs {
+  const cf* in;
+  cf* out;
+  cf* wslots;                    // 16 slots of N points (indexed by XCC id)
+  XcdCtl* ctl;
+  unsigned* sticky_error;        // device-wide error word (bit 0: registration timeout, bit 1: barrier timeout)
+  const cf* tw_a;                // stage tables of the pass A / pass B line configs
+  const cf* tw_b;
+  const cf* tw_lo;               // four-step roots: e^{-2 pi i m/N} = HI[m >> shift] * LO[m & mask]
+  const cf* tw_hi;
+  long long num_transforms;
+  long long N;                   // N1 * N2
+  float scale;
+  int fs_shift;
+  unsigned fs_lo_mask;
+  unsigned spin_limit;           // polls before a wait gives up
+};
+
+// roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by
+// multiplying with the per-thread step e^{-2 pi i (N2/R0) k1/N} (error <= 8 roundings; the hoisted form of
+// kern_lines.hpp would need 64 VGPRs per row tile, and a workgroup owns two)
+template <class C>
+MI_DEV void fourstep_roots_chain(cf (&fsw)[C::E], const XcdFusedArgs& a, unsigned k1, int u) {
+  using I = StageInfo<C, 0>;
+  const auto root = [&](unsigned m) { return cmul(a.tw_hi[m >> a.fs_shift], a.tw_lo[m & a.fs_lo_mask]); };
+  const cf step = root(k1 * (unsigned)(C::N / I::R));
+#pragma unroll
+  for (int b = 0; b < I::NB; ++b) {
+#pragma unroll
+    for (int q = 0; q < I::R; ++q) {
+      if ((q & 7) == 0) fsw[b * I::R + q] = root(k1 * (unsigned)(u + b * C::TPL + q * (C::N / I::R)));
+      else fsw[b * I::R + q] = cmul(fsw[b * I::R + q - 1], step);
+    }
+  }
+}
+
+MI_DEV bool xcd_group_barrier(XcdCtl* ctl, unsigned xcc, unsigned target, unsigned spin_limit, unsigned* sticky, unsigned* s_flag) {
+  MI_WAIT_VMEM();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MI_ATOMIC_ADD_U32(&ctl->bar[xcc][0], 1u);
+    unsigned ok = 0;
+    for (unsigned it = 0; it < spin_limit; ++it) {
+      if (MI_ATOMIC_LOAD_U32(&ctl->bar[xcc][0]) >= target) { ok = 1; break; }
+      MI_SLEEP();
+    }
+    MI_ACQUIRE_AGENT();
+    if (!ok) MI_ATOMIC_OR_U32(sticky, 2u);
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+template <class CA, class CB>
+__global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFusedArgs f) {
+  static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
+  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL && CB::OUT_COL, "PASS_A then PASS_B");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
+  cf* tw_a = lds + DATA;
+  cf* tw_b = tw_a + CA::TW_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw_b + CB::TW_ELEMS);   // [0] xcc, [1] rank, [2] group size, [3] ok, [4] group index, [5] groups, [6] barrier flag
+  const int t = threadIdx.x;
+  for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
+  for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i];
+
+  // ---- registration ----
+  if (t == 0) {
+    const unsigned x = MI_XCC_ID() & 15u;
+    const unsigned r = MI_ATOMIC_ADD_U32(&f.ctl->reg_xcd[x], 1u);
+    MI_ATOMIC_ADD_U32(&f.ctl->reg_total, 1u);
+    unsigned ok = 0;
+    for (unsigned it = 0; it < f.spin_limit; ++it) {
+      if (MI_ATOMIC_LOAD_U32(&f.ctl->reg_total) >= gridDim.x) { ok = 1; break; }
+      MI_SLEEP();
+    }
+    unsigned groups = 0, gi = 0;
+    for (unsigned k = 0; k < 16; ++k) {
+      const unsigned cnt = MI_ATOMIC_LOAD_U32(&f.ctl->reg_xcd[k]);
+      if (k == x) gi = groups;
+      if (cnt) ++groups;
+    }
+    s_words[0] = x; s_words[1] = r; s_words[2] = MI_ATOMIC_LOAD_U32(&f.ctl->reg_xcd[x]); s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
+    if (!ok) MI_ATOMIC_OR_U32(f.sticky_error, 1u);
+  }
+  __syncthreads();
+  if (!s_words[3]) return;
+  const unsigned xcc = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+
+  const long long N1 = CA::N, N2 = CB::N;
+  LineArgs aa{}, ab{};
+  aa.tw = f.tw_a; aa.num_tiles = N2 / CA::T; aa.num_lines = N2;
+  aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
+  ab.tw = f.tw_b; ab.num_tiles = N1 / CB::T; ab.num_lines = N1;
+  ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
+  cf* const W = f.wslots + (size_t)xcc * (size_t)f.N;
+  unsigned bar = 0;
+
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups) {
+    // ---- phase A: column FFTs of transform tr into this XCD's workspace slot ----
+    aa.in = f.in + tr * f.N; aa.out = W;
+    for (long long tile = rank; tile < aa.num_tiles; tile += gsize) {
+      cf v[CA::E];
+      stage_read<CA, 0>(v, aa, tile, t, lds);
+      stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
+      if constexpr (CA::NSTAGES >= 2) {
+        __syncthreads();
+        stage_read<CA, 1>(v, aa, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CA, 1>(v, aa, tile, t, lds, tw_a, nullptr);
+      }
+      if constexpr (CA::NSTAGES == 3) {
+        __syncthreads();
+        stage_read<CA, 2>(v, aa, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CA, 2>(v, aa, tile, t, lds, tw_a, nullptr);
+      }
+      __syncthreads();   // LDS is re-used by the next tile
+    }
+    if (!xcd_group_barrier(f.ctl, xcc, (++bar) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B: four-step roots on load, row FFTs, transposed store to the output ----
+    ab.in = W; ab.out = f.out + tr * f.N;
+    for (long long tile = rank; tile < ab.num_tiles; tile += gsize) {
+      cf v[CB::E];
+      stage_read<CB, 0>(v, ab, tile, t, lds);
+      {
+        int line, u; thread_map<CB, 0>(t, line, u);
+        cf fsw[CB::E];
+        fourstep_roots_chain<CB>(fsw, f, (unsigned)(tile * CB::T + line), u);
+#pragma unroll
+        for (int e = 0; e < CB::E; ++e) v[e] = cmul(v[e], fsw[e]);
+      }
+      stage_compute_write<CB, 0>(v, ab, tile, t, lds, tw_b, nullptr);
+      if constexpr (CB::NSTAGES >= 2) {
+        __syncthreads();
+        stage_read<CB, 1>(v, ab, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CB, 1>(v, ab, tile, t, lds, tw_b, nullptr);
+      }
+      if constexpr (CB::NSTAGES == 3) {
+        __syncthreads();
+        stage_read<CB, 2>(v, ab, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CB, 2>(v, ab, tile, t, lds, tw_b, nullptr);
+      }
+      __syncthreads();
+    }
+    if (!xcd_group_barrier(f.ctl, xcc, (++bar) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+  }
+}
+
+template <class CA, class CB> struct XcdFusedCfg {
+  static constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
+  static constexpr int LDS_BYTES = (DATA + CA::TW_ELEMS + CB::TW_ELEMS) * 8 + 64;
+  static constexpr int THREADS = CA::THREADS;
+  static_assert(LDS_BYTES <= 160 * 1024, "fused tile does not fit LDS");
+};
+
+}  // namespace mi355

@@ -79,11 +79,32 @@ const std::vector<ConvKernelMeta>& conv_kernel_registry() {
   return reg;
 }
 
+const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
+  static const std::vector<XcdKernelMeta> reg = [] {
+    std::vector<XcdKernelMeta> r;
+    int id = 0;
+#define X(N1, A0, A1, A2, N2, B0, B1, B2)                                                                  \
+  for (int inv = 0; inv < 2; ++inv) {                                                                     \
+    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, 16, true, true, inv != 0, false, 0);           \
+    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, 16, false, true, false, inv != 0, 0);          \
+    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, inv != 0, ma.threads, 0};                   \
+    const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
+    m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + mb.tw_elems) * 8 + 64;                             \
+    r.push_back(m);                                                                                       \
+  }
+    MI355_XCD_KERNEL_LIST(X)
+#undef X
+    return r;
+  }();
+  return reg;
+}
+
 PlannerOptions planner_options_from_env() {
   PlannerOptions o;
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   return o;
 }
 
@@ -189,7 +210,7 @@ struct Builder {
       return MI355FFT_OK;
     }
     const bool p2 = is_pow2(N);
-    if (!opt.force_generic && S == 1 && p2 && N <= 4096) {
+    if (!opt.force_generic && S == 1 && p2 && N <= 4096 && !(opt.xcd_fused == 2 && N == 4096)) {   // xcd_fused == 2: emulation tests
       const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
       if (m) {
         Step& st = push(ST_LINES);
@@ -215,6 +236,33 @@ struct Builder {
         st.f[0] = scale;
         st.grid = lines_grid(*m, tiles);
         ir.route += "columns[N=" + std::to_string(N) + ",S=" + std::to_string(S) + "] ";
+        return MI355FFT_OK;
+      }
+    }
+    if (!opt.force_generic && S == 1 && p2 && N >= 4096 && opt.xcd_fused && !opt.only_pass) {
+      // XCD-fused route: both passes in one persistent launch, one transform per XCD at a time (kern_xcd.hpp)
+      const int lgf = lg2(N);
+      const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
+      const XcdKernelMeta* xm = nullptr;
+      for (const auto& m : xcd_kernel_registry()) if (m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
+      if (xm && (N > 4096 || opt.xcd_fused == 2)) {
+        const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], 16, true, true, false, false, 0);
+        const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], 16, false, true, false, false, 0);
+        const PtrRef wslots = alloc_work((uint64_t)16 * N * 8);
+        const PtrRef ctl = alloc_work(4096);
+        std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, N >> 10));
+        for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
+        for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
+        const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
+        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 1024; z.grid = 1;
+        Step& st = push(ST_XCD_FUSED);
+        st.variant = xm->id;
+        st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+        st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023;
+        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off;
+        st.f[0] = scale;
+        st.grid = (unsigned)opt.compute_units;     // one workgroup per CU (LDS-limited), all co-resident
+        ir.route += "xcd-fused[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }

@@ -37,6 +37,13 @@ const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool sw
   X(64, 8, 8, 4) X(64, 8, 8, 16) X(128, 16, 8, 4) X(128, 16, 8, 16) X(256, 16, 16, 4) X(256, 16, 16, 16) \
   X(512, 32, 16, 4) X(512, 32, 16, 16) X(1024, 32, 32, 4) X(1024, 32, 32, 16)
 struct ConvKernelMeta { int id, N, R0, R1, TL; };
+
+// XCD-fused four-step kernels (kern_xcd.hpp): X(N1, R0a, R1a, R2a, N2, R0b, R1b, R2b), T = 16 on both passes; each is built
+// forward and inverse.  (64 x 64 exists for the CPU emulation tests.)
+#define MI355_XCD_KERNEL_LIST(X) \
+  X(64, 8, 8, 1, 64, 8, 8, 1) X(512, 32, 16, 1, 512, 32, 16, 1) X(1024, 32, 32, 1, 1024, 32, 32, 1)
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3]; bool inverse; int threads, lds_bytes; };
+const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
 enum BufId : int { BUF_NONE = -1, BUF_INPUT = 0, BUF_OUTPUT = 1, BUF_WORK = 2, BUF_KERNEL = 3, BUF_TABLE = 4 };
@@ -51,7 +58,7 @@ struct PtrRef {
 
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
-  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED
 };
 
 // One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).
@@ -78,6 +85,7 @@ struct PlannerOptions {
   uint64_t chunk_bytes = 1ull << 30;   // two-pass: bytes of inter-pass intermediate per launch pair (measured: larger is faster)
   int compute_units = 256;
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
+  int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };
 PlannerOptions planner_options_from_env();

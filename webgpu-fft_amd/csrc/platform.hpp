@@ -19,6 +19,14 @@
     __builtin_amdgcn_wave_barrier();                         \
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
   } while (0)
+// inter-workgroup primitives of the XCD-fused kernel (kern_xcd.hpp)
+#define MI_XCC_ID() (__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 0xf)
+#define MI_ATOMIC_ADD_U32(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MI_ATOMIC_LOAD_U32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MI_ATOMIC_OR_U32(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MI_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define MI_ACQUIRE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define MI_SLEEP() __builtin_amdgcn_s_sleep(1)
 #else
 #include <cmath>
 #include <cstdint>
@@ -27,7 +35,9 @@ namespace emu {
 struct dim3_t { unsigned x = 1, y = 1, z = 1; };
 extern thread_local dim3_t t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local char* t_smem;
+extern unsigned g_xcds;   // emulated XCD count: block b reports XCC id b % g_xcds
 void sync_threads();
+void yield_thread();
 }  // namespace emu
 #define __global__
 #define __device__
@@ -42,5 +52,12 @@ void sync_threads();
 #define __syncthreads() emu::sync_threads()
 #define MI_SMEM_DECL(name) char* name = emu::t_smem
 #define MI_SMEM_DECL_STATIC(type, name, n) type* name = reinterpret_cast<type*>(emu::t_smem)
+#define MI_XCC_ID() (emu::t_blockIdx.x % emu::g_xcds)
+#define MI_ATOMIC_ADD_U32(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define MI_ATOMIC_LOAD_U32(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define MI_ATOMIC_OR_U32(p, v) __atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST)
+#define MI_WAIT_VMEM() do { } while (0)
+#define MI_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define MI_SLEEP() emu::yield_thread()   /* bounded spins must outlast thread start-up of the other emulated blocks */
 #define MI_WAVE_SYNC() emu::sync_threads() /* emulated waves are not lock-step: use the block barrier */
 #endif
