@@ -243,13 +243,14 @@ def test_r2c_c2r_whdcn_lanes(oracle):
     assert float(np.max(np.abs(back - wantr))) < 2e-6
 
 
-@pytest.mark.parametrize("cus,xcds", [(2, 2), (4, 2), (6, 3), (3, 1)])
-def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds):
+@pytest.mark.parametrize("cus,xcds,split", [(2, 2, 1), (4, 2, 1), (6, 3, 1), (3, 1, 1), (8, 2, 2), (8, 1, 4), (6, 1, 4)])
+def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
     """both passes in one persistent launch; workgroups grouped by (emulated) XCC id synchronise through global
     counters: blocks run concurrently under emulation.  N = 64 x 64 is the test instance of the kernel template."""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
     n, batch = 4096, 5
     x = oracle.random_complex_batch(n, batch, 0xF00D + cus).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):

@@ -35,19 +35,14 @@
 
 namespace mi355 {
 
-MI_DEV cf ld_stream(const cf* p) {
-#if MI355_NT_GLOBAL
-  return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
+// NT: per-call-site override (the XCD-fused kernel streams x and the output past the L2 it wants to keep W in)
+template <bool NT = false> MI_DEV cf ld_stream(const cf* p) {
+  if constexpr (NT || MI355_NT_GLOBAL) return __builtin_nontemporal_load(p);
+  else return *p;
 }
-MI_DEV void st_stream(cf* p, cf v) {
-#if MI355_NT_GLOBAL
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
+template <bool NT = false> MI_DEV void st_stream(cf* p, cf v) {
+  if constexpr (NT || MI355_NT_GLOBAL) __builtin_nontemporal_store(v, p);
+  else *p = v;
 }
 
 // four-step twiddle e^{-2 pi i (line index in its group) * (element index) / Ntot}:
@@ -159,7 +154,7 @@ MI_DEV void fourstep_in_roots(cf (&fsw)[C::E], const LineArgs& a, long long tile
   }
 }
 
-template <class C, int S>
+template <class C, int S, bool NT = false>
 MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, const cf* lds) {
   using I = StageInfo<C, S>;
   int line, u; thread_map<C, S>(t, line, u);
@@ -177,7 +172,7 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
 #pragma unroll
       for (int q = 0; q < I::R; ++q) {
         const cf* pq = p + (unsigned)(b * C::TPL + q * (C::N / I::R)) * es;   // uniform
-        v[b * I::R + q] = cswap_if<C::SWAP_IN>(ld_stream(pq + voff));
+        v[b * I::R + q] = cswap_if<C::SWAP_IN>(ld_stream<NT>(pq + voff));
       }
     }
   } else {
@@ -190,7 +185,7 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
   }
 }
 
-template <class C, int S>
+template <class C, int S, bool NT = false>
 MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile, int t, cf* lds, const cf* tw_lds, const cf* lo_lds) {
   using I = StageInfo<C, S>;
   int line, u; thread_map<C, S>(t, line, u);
@@ -234,7 +229,7 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
         // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
         cf* pq = po + (unsigned)(b * C::TPL + q * I::NSP) * es;
         const unsigned voff = (unsigned)line * ls + (unsigned)u * es;
-        if (live) st_stream(pq + voff, cswap_if<C::SWAP_OUT>(r));
+        if (live) st_stream<NT>(pq + voff, cswap_if<C::SWAP_OUT>(r));
       } else {
         lds[lds_index<C>(line, oidx)] = w[q];
       }

@@ -16,7 +16,7 @@
 //     phase A  column tiles r, r+s, ... of x_t -> W[xcc]      (kern_lines.hpp PASS_A stages)
 //     XCD barrier
 //     phase B  row tiles r, r+s, ... of W[xcc] -> out_t       (PASS_B stages, four-step roots generated per tile)
-//     XCD barrier (W[xcc] may be overwritten)
+//   (W[xcc] is double-buffered, so the A/B barrier of the next transform is the only one needed)
 // Hand-off protocol (same-XCD by construction, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"): producers'
 // stores are complete in the shared L2 after `s_waitcnt vmcnt(0)`; one lane per workgroup adds to the group's monotonic
 // counter and polls it with relaxed agent-scope loads; every consumer workgroup then invalidates its CU's L1 with an
@@ -25,18 +25,24 @@
 #pragma once
 #include "kern_lines.hpp"
 
+#ifndef MI355_XCD_NT
+#define MI355_XCD_NT 0   /* measured on one box: 164 GPoints/s off, 162 on (profiles/r01_xcd_fused_ab.log) */
+#endif
+
 namespace mi355 {
+
+constexpr bool XCD_NT = MI355_XCD_NT != 0;   // nontemporal x loads / output stores in the fused kernel
 
 struct XcdCtl {                  // zeroed by a memset step before every launch
   unsigned reg_total;
   unsigned reg_xcd[16];
-  unsigned bar[16][16];          // one 64-byte line per XCC id
+  unsigned bar[64][16];          // one 64-byte line per group (XCC id x split)
 };
 
 struct XcdFusedArgs {
   const cf* in;
   cf* out;
-  cf* wslots;                    // 16 slots of N points (indexed by XCC id)
+  cf* wslots;                    // 128 slots of N points (two per group; up to 4 groups per XCC id)
   XcdCtl* ctl;
   unsigned* sticky_error;        // device-wide error word (bit 0: registration timeout, bit 1: barrier timeout)
   const cf* tw_a;                // stage tables of the pass A / pass B line configs
@@ -49,6 +55,7 @@ struct XcdFusedArgs {
   int fs_shift;
   unsigned fs_lo_mask;
   unsigned spin_limit;           // polls before a wait gives up
+  unsigned split;                // groups per XCD (1, 2 or 4): the workgroups of an XCD are divided by rank
 };
 
 // roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by
@@ -69,14 +76,19 @@ MI_DEV void fourstep_roots_chain(cf (&fsw)[C::E], const XcdFusedArgs& a, unsigne
   }
 }
 
-MI_DEV bool xcd_group_barrier(XcdCtl* ctl, unsigned xcc, unsigned target, unsigned spin_limit, unsigned* sticky, unsigned* s_flag) {
+// split barrier over the workgroups of one XCD.  arrive: this workgroup's stores are complete in the shared L2
+// (s_waitcnt vmcnt(0) in every wave, then the workgroup barrier), one lane bumps the group counter.  wait: one lane polls
+// (relaxed agent-scope loads, bounded), then an agent-scope acquire drops this CU's L1 before anyone reads.
+MI_DEV void xcd_arrive(unsigned* counter) {
   MI_WAIT_VMEM();
   __syncthreads();
+  if (threadIdx.x == 0) MI_ATOMIC_ADD_U32(counter, 1u);
+}
+MI_DEV bool xcd_wait(unsigned* counter, unsigned target, unsigned spin_limit, unsigned* sticky, unsigned* s_flag) {
   if (threadIdx.x == 0) {
-    MI_ATOMIC_ADD_U32(&ctl->bar[xcc][0], 1u);
     unsigned ok = 0;
     for (unsigned it = 0; it < spin_limit; ++it) {
-      if (MI_ATOMIC_LOAD_U32(&ctl->bar[xcc][0]) >= target) { ok = 1; break; }
+      if (MI_ATOMIC_LOAD_U32(counter) >= target) { ok = 1; break; }
       MI_SLEEP();
     }
     MI_ACQUIRE_AGENT();
@@ -96,7 +108,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
   cf* tw_a = lds + DATA;
   cf* tw_b = tw_a + CA::TW_ELEMS;
-  unsigned* s_words = reinterpret_cast<unsigned*>(tw_b + CB::TW_ELEMS);   // [0] xcc, [1] rank, [2] group size, [3] ok, [4] group index, [5] groups, [6] barrier flag
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw_b + CB::TW_ELEMS);   // [0] group slot, [1] rank, [2] group size, [3] ok, [4] group index, [5] groups, [6] barrier flag
   const int t = threadIdx.x;
   for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
   for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i];
@@ -111,18 +123,27 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       if (MI_ATOMIC_LOAD_U32(&f.ctl->reg_total) >= gridDim.x) { ok = 1; break; }
       MI_SLEEP();
     }
-    unsigned groups = 0, gi = 0;
+    // an XCD's workgroups may be split into up to 4 groups by rank (each with its own workspace slots and barrier counter):
+    // smaller groups run out of phase with each other inside one XCD at the price of sharing its L2
+    const unsigned split = f.split ? f.split : 1u;
+    unsigned groups = 0, gi = 0, mine = 0, sub = 0, gsz = 0;
     for (unsigned k = 0; k < 16; ++k) {
       const unsigned cnt = MI_ATOMIC_LOAD_U32(&f.ctl->reg_xcd[k]);
-      if (k == x) gi = groups;
-      if (cnt) ++groups;
+      if (!cnt) continue;
+      const unsigned per = (cnt + split - 1u) / split, nsub = (cnt + per - 1u) / per;
+      if (k == x) {
+        sub = r / per; mine = r - sub * per;
+        gsz = (sub + 1u) * per <= cnt ? per : cnt - sub * per;
+        gi = groups + sub;
+      }
+      groups += nsub;
     }
-    s_words[0] = x; s_words[1] = r; s_words[2] = MI_ATOMIC_LOAD_U32(&f.ctl->reg_xcd[x]); s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
+    s_words[0] = x * 4u + sub; s_words[1] = mine; s_words[2] = gsz; s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
     if (!ok) MI_ATOMIC_OR_U32(f.sticky_error, 1u);
   }
   __syncthreads();
   if (!s_words[3]) return;
-  const unsigned xcc = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
   const long long N1 = CA::N, N2 = CB::N;
   LineArgs aa{}, ab{};
@@ -130,15 +151,20 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = N1 / CB::T; ab.num_lines = N1;
   ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
-  cf* const W = f.wslots + (size_t)xcc * (size_t)f.N;
-  unsigned bar = 0;
-
-  for (long long tr = gidx; tr < f.num_transforms; tr += groups) {
+  // Two workspace slots per XCD, alternated per transform: phase B(k) runs right after phase A(k) so that it finds as much
+  // of the intermediate as possible still in this XCD's L2, and the barrier between A(k+1) and B(k+1) also orders "everyone
+  // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one XCD barrier per transform.
+  // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, evicts the intermediate of k from L2 and
+  // loses more than it gains: 150 vs 165 GPoints/s at N = 2^20.)
+  cf* const W0 = f.wslots + (size_t)(2u * gslot) * (size_t)f.N;
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(k & 1u) * (size_t)f.N;
     // ---- phase A: column FFTs of transform tr into this XCD's workspace slot ----
     aa.in = f.in + tr * f.N; aa.out = W;
     for (long long tile = rank; tile < aa.num_tiles; tile += gsize) {
       cf v[CA::E];
-      stage_read<CA, 0>(v, aa, tile, t, lds);
+      stage_read<CA, 0, XCD_NT>(v, aa, tile, t, lds);       // x streams past the L2
       stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
       if constexpr (CA::NSTAGES >= 2) {
         __syncthreads();
@@ -154,7 +180,8 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       }
       __syncthreads();   // LDS is re-used by the next tile
     }
-    if (!xcd_group_barrier(f.ctl, xcc, (++bar) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     // ---- phase B: four-step roots on load, row FFTs, transposed store to the output ----
     ab.in = W; ab.out = f.out + tr * f.N;
     for (long long tile = rank; tile < ab.num_tiles; tile += gsize) {
@@ -167,22 +194,21 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
 #pragma unroll
         for (int e = 0; e < CB::E; ++e) v[e] = cmul(v[e], fsw[e]);
       }
-      stage_compute_write<CB, 0>(v, ab, tile, t, lds, tw_b, nullptr);
+      stage_compute_write<CB, 0, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);
       if constexpr (CB::NSTAGES >= 2) {
         __syncthreads();
         stage_read<CB, 1>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 1>(v, ab, tile, t, lds, tw_b, nullptr);
+        stage_compute_write<CB, 1, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);   // output streams past the L2
       }
       if constexpr (CB::NSTAGES == 3) {
         __syncthreads();
         stage_read<CB, 2>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 2>(v, ab, tile, t, lds, tw_b, nullptr);
+        stage_compute_write<CB, 2, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);
       }
       __syncthreads();
     }
-    if (!xcd_group_barrier(f.ctl, xcc, (++bar) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
   }
 }
 

@@ -105,6 +105,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_split = v; }
   return o;
 }
 
@@ -248,18 +249,19 @@ struct Builder {
       if (xm && (N > 4096 || opt.xcd_fused == 2)) {
         const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], 16, true, true, false, false, 0);
         const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], 16, false, true, false, false, 0);
-        const PtrRef wslots = alloc_work((uint64_t)16 * N * 8);
-        const PtrRef ctl = alloc_work(4096);
+        const int64_t split = opt.xcd_split > 0 ? opt.xcd_split : 1;
+        const PtrRef wslots = alloc_work((uint64_t)128 * N * 8);   // two slots per group, up to 4 groups per XCC id
+        const PtrRef ctl = alloc_work(8192);
         std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, N >> 10));
         for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
         for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
         const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
-        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 1024; z.grid = 1;
+        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 2048; z.grid = 1;
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
         st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023;
-        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off;
+        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split;
         st.f[0] = scale;
         st.grid = (unsigned)opt.compute_units;     // one workgroup per CU (LDS-limited), all co-resident
         ir.route += "xcd-fused[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";

@@ -16,7 +16,7 @@ from .layout import (createFftConvBatchMajorChannelLanePreset, createFftConvChan
                      createFftConvKernelMajorChannelLanePreset, resolve_plan_options)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libmi355fft.so"))
+LIB_PATH = os.environ.get("MI355FFT_LIB") or os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libmi355fft.so"))   # env: A/B builds
 _LIB = None
 
 
