@@ -26,7 +26,7 @@
 #include "kern_lines.hpp"
 
 #ifndef MI355_XCD_NT
-#define MI355_XCD_NT 0   /* measured on one box: 164 GPoints/s off, 162 on (profiles/r01_xcd_fused_ab.log) */
+#define MI355_XCD_NT 1   /* same-box A/B with two groups per XCD: 185-188 GPoints/s on, 175-182 off (profiles/r01_xcd_fused_ab.log) */
 #endif
 
 namespace mi355 {

@@ -105,7 +105,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
-  if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_split = v; }
+  if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 1 && v <= 4) o.xcd_split = v; }
   return o;
 }
 

@@ -86,7 +86,7 @@ struct PlannerOptions {
   int compute_units = 256;
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
-  int xcd_split = 1;                   // groups per XCD in the fused kernel (1, 2, 4)
+  int xcd_split = 2;                   // groups per XCD in the fused kernel (1..4); 2 measured best (profiles/r01_xcd_fused_ab.log)
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };
 PlannerOptions planner_options_from_env();
