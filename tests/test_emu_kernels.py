@@ -64,6 +64,17 @@ def test_c2c_two_pass_hoisted_fourstep_roots(oracle, lg, grid, monkeypatch):
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"hoisted 2^{lg} {direction}")
 
 
+def test_c2c_two_pass_2p22(oracle):
+    """the largest power of two of the route: 2048 x 2048, three-stage column tiles of 8 in pass A"""
+    n = 1 << 22
+    x = oracle.random_complex_batch(n, 1, 0xB222).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc = _abi.make_desc("c2c", [n], 1, direction, "none")
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith("two-pass[N=2048x2048") and launches == 2, route
+        check(got, oracle.c2c_ref_batch(x, [n], 1, direction, "none"), f"two-pass 2^22 {direction}")
+
+
 @pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 24, 96, 105, 210, 1001, 8 * 13 * 11])
 def test_c2c_generic_mixed_radix(oracle, n):
     batch = 2
@@ -261,3 +272,20 @@ def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
     desc = _abi.make_desc("c2c", [n], batch, "forward", "unitary", in_place=True)
     got, route, _ = emu.run_plan(desc, x, x.size)
     check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")
+
+
+@pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (21, "1024x2048")])
+def test_c2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
+    """the product instances of the fused kernel whose two passes use different tile widths (512x1024: 32-column
+    tiles in pass A; 1024x2048: 8-row tiles and a three-stage row FFT in pass B), forward and inverse"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "4")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", "2")
+    n, batch = 1 << lg, 3
+    x = oracle.random_complex_batch(n, batch, 0xBEEF + lg).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith(f"xcd-fused[N={label}]") and launches == 2
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused {label} {direction}")

@@ -119,14 +119,33 @@ def test_c2c_in_place_and_offsets(fft, dev, oracle):
     out.destroy()
 
 
-@pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21])
-def test_c2c_two_pass(fft, dev, oracle, lg):
+FUSED_LG = (18, 19, 20, 21)   # MI355_XCD_KERNEL_LIST (plan.hpp)
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
+    """four-step sizes on both routes: the two-launch route and (where an instance exists) the XCD-fused launch"""
+    if fused and lg not in FUSED_LG:
+        pytest.skip("no fused instance")
+    monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     n, batch = 1 << lg, 3 if lg <= 18 else 2
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith("two-pass[") or route.startswith("xcd-fused[")
-        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"two-pass 2^{lg} {direction}")
+        assert route.startswith("xcd-fused[" if fused else "two-pass[")
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
+
+
+@pytest.mark.parametrize("lg,batch", [(18, 150), (19, 75), (21, 37)])
+def test_c2c_fused_many_transforms(fft, dev, oracle, lg, batch):
+    """more transforms than groups: every group walks several transforms and alternates its two workspace slots"""
+    n = 1 << lg
+    x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
+    for direction in ("forward", "inverse"):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
+        assert route.startswith("xcd-fused[") and launches == 2
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"fused 2^{lg} x{batch} {direction}")
 
 
 def test_c2c_large_golden_samples(fft, dev, oracle, manifest):

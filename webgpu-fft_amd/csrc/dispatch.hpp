@@ -74,17 +74,17 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
 // XCD-fused four-step kernels live in their own translation unit in the product build (lines_fam_xcd.hip)
 template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
   int cur = 0;
-#define X(N1, A0, A1, A2, N2, B0, B1, B2)                                                          \
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
   if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, 16, true, true, false, false, 0>;                          \
-    using CB = LineCfg<N2, B0, B1, B2, 16, false, true, false, false, 0>;                         \
+    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
+    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
     using F = XcdFusedCfg<CA, CB>;                                                                \
     l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
     return true;                                                                                  \
   }                                                                                               \
   if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, 16, true, true, true, false, 0>;                           \
-    using CB = LineCfg<N2, B0, B1, B2, 16, false, true, false, true, 0>;                          \
+    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, true, false, 0>;                           \
+    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, true, 0>;                          \
     using F = XcdFusedCfg<CA, CB>;                                                                \
     l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
     return true;                                                                                  \

@@ -42,7 +42,7 @@ struct XcdCtl {                  // zeroed by a memset step before every launch
 struct XcdFusedArgs {
   const cf* in;
   cf* out;
-  cf* wslots;                    // 128 slots of N points (two per group; up to 4 groups per XCC id)
+  cf* wslots;                    // 32*split slots of N points (two per group, `split` groups per XCC id)
   XcdCtl* ctl;
   unsigned* sticky_error;        // device-wide error word (bit 0: registration timeout, bit 1: barrier timeout)
   const cf* tw_a;                // stage tables of the pass A / pass B line configs
@@ -62,16 +62,25 @@ struct XcdFusedArgs {
 // multiplying with the per-thread step e^{-2 pi i (N2/R0) k1/N} (error <= 8 roundings; the hoisted form of
 // kern_lines.hpp would need 64 VGPRs per row tile, and a workgroup owns two)
 template <class C>
-MI_DEV void fourstep_roots_chain(cf (&fsw)[C::E], const XcdFusedArgs& a, unsigned k1, int u) {
+MI_DEV void fourstep_apply_chain(cf (&v)[C::E], const XcdFusedArgs& a, unsigned k1, int u) {
   using I = StageInfo<C, 0>;
+  constexpr int NA = (I::R + 7) / 8;   // anchors per butterfly
   const auto root = [&](unsigned m) { return cmul(a.tw_hi[m >> a.fs_shift], a.tw_lo[m & a.fs_lo_mask]); };
   const cf step = root(k1 * (unsigned)(C::N / I::R));
 #pragma unroll
   for (int b = 0; b < I::NB; ++b) {
+    cf anchor[NA];
 #pragma unroll
-    for (int q = 0; q < I::R; ++q) {
-      if ((q & 7) == 0) fsw[b * I::R + q] = root(k1 * (unsigned)(u + b * C::TPL + q * (C::N / I::R)));
-      else fsw[b * I::R + q] = cmul(fsw[b * I::R + q - 1], step);
+    for (int g = 0; g < NA; ++g) anchor[g] = root(k1 * (unsigned)(u + b * C::TPL + 8 * g * (C::N / I::R)));
+#pragma unroll
+    for (int g = 0; g < NA; ++g) {
+      cf w = anchor[g];
+#pragma unroll
+      for (int j = 0; j < 8 && 8 * g + j < I::R; ++j) {
+        cf& x = v[b * I::R + 8 * g + j];
+        x = cmul(x, w);
+        if (j < 7) w = cmul(w, step);
+      }
     }
   }
 }
@@ -138,7 +147,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       }
       groups += nsub;
     }
-    s_words[0] = x * 4u + sub; s_words[1] = mine; s_words[2] = gsz; s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
+    s_words[0] = x * split + sub; s_words[1] = mine; s_words[2] = gsz; s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
     if (!ok) MI_ATOMIC_OR_U32(f.sticky_error, 1u);
   }
   __syncthreads();
@@ -151,11 +160,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = N1 / CB::T; ab.num_lines = N1;
   ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
-  // Two workspace slots per XCD, alternated per transform: phase B(k) runs right after phase A(k) so that it finds as much
-  // of the intermediate as possible still in this XCD's L2, and the barrier between A(k+1) and B(k+1) also orders "everyone
-  // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one XCD barrier per transform.
-  // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, evicts the intermediate of k from L2 and
-  // loses more than it gains: 150 vs 165 GPoints/s at N = 2^20.)
+  // Two workspace slots per group, alternated per transform: the barrier between A(k+1) and B(k+1) also orders "everyone
+  // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one group barrier per transform.
+  // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, loses more than it gains: 150 vs 165
+  // GPoints/s at N = 2^20.)
   cf* const W0 = f.wslots + (size_t)(2u * gslot) * (size_t)f.N;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
@@ -189,10 +197,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       stage_read<CB, 0>(v, ab, tile, t, lds);
       {
         int line, u; thread_map<CB, 0>(t, line, u);
-        cf fsw[CB::E];
-        fourstep_roots_chain<CB>(fsw, f, (unsigned)(tile * CB::T + line), u);
-#pragma unroll
-        for (int e = 0; e < CB::E; ++e) v[e] = cmul(v[e], fsw[e]);
+        fourstep_apply_chain<CB>(v, f, (unsigned)(tile * CB::T + line), u);
       }
       stage_compute_write<CB, 0, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);
       if constexpr (CB::NSTAGES >= 2) {

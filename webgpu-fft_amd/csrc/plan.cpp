@@ -83,11 +83,11 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
   static const std::vector<XcdKernelMeta> reg = [] {
     std::vector<XcdKernelMeta> r;
     int id = 0;
-#define X(N1, A0, A1, A2, N2, B0, B1, B2)                                                                  \
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
   for (int inv = 0; inv < 2; ++inv) {                                                                     \
-    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, 16, true, true, inv != 0, false, 0);           \
-    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, 16, false, true, false, inv != 0, 0);          \
-    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, inv != 0, ma.threads, 0};                   \
+    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, inv != 0, false, 0);           \
+    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, true, false, inv != 0, 0);          \
+    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, inv != 0, ma.threads, 0};           \
     const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
     m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + mb.tw_elems) * 8 + 64;                             \
     r.push_back(m);                                                                                       \
@@ -247,10 +247,10 @@ struct Builder {
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry()) if (m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2)) {
-        const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], 16, true, true, false, false, 0);
-        const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], 16, false, true, false, false, 0);
+        const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+        const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
         const int64_t split = opt.xcd_split > 0 ? opt.xcd_split : 1;
-        const PtrRef wslots = alloc_work((uint64_t)128 * N * 8);   // two slots per group, up to 4 groups per XCC id
+        const PtrRef wslots = alloc_work((uint64_t)(32 * split) * N * 8);   // two slots per group, `split` groups per XCC id (16 ids)
         const PtrRef ctl = alloc_work(8192);
         std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, N >> 10));
         for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);

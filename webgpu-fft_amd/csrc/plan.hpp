@@ -38,11 +38,13 @@ const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool sw
   X(512, 32, 16, 4) X(512, 32, 16, 16) X(1024, 32, 32, 4) X(1024, 32, 32, 16)
 struct ConvKernelMeta { int id, N, R0, R1, TL; };
 
-// XCD-fused four-step kernels (kern_xcd.hpp): X(N1, R0a, R1a, R2a, N2, R0b, R1b, R2b), T = 16 on both passes; each is built
-// forward and inverse.  (64 x 64 exists for the CPU emulation tests.)
+// XCD-fused four-step kernels (kern_xcd.hpp): X(N1, R0a, R1a, R2a, Ta, N2, R0b, R1b, R2b, Tb); the tile widths are chosen so
+// that both passes use the same workgroup size; each is built forward and inverse.  (64 x 64 exists for the CPU
+// emulation tests.)  N = 2^18, 2^19, 2^20, 2^21 (the c2c half of r2c/c2r N = 2^22).
 #define MI355_XCD_KERNEL_LIST(X) \
-  X(64, 8, 8, 1, 64, 8, 8, 1) X(512, 32, 16, 1, 512, 32, 16, 1) X(1024, 32, 32, 1, 1024, 32, 32, 1)
-struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3]; bool inverse; int threads, lds_bytes; };
+  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
+  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; };
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
