@@ -62,7 +62,11 @@ def run_plan(fft, dev, opts, x, out_floats, kernel=None, out_init=None, in_place
 def check(oracle, got, want, what, atol=3e-4, rtol=3e-4, tol=TOL):
     l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
     assert l2 <= tol and mx <= tol, f"{what}: rel_l2={l2:.3e} rel_max={mx:.3e}"
-    oracle.assert_close_elementwise(got, want, atol, rtol, what)
+    # elementwise |got - want| <= atol + rtol*|want| as the reference's suites do; their sizes keep the output rms near 1-20,
+    # so for long unnormalised transforms (rms = sqrt(N/12): 418 at N = 2^21, where one f32 ulp is already 3e-5) atol is
+    # scaled by the rms above 64 — otherwise the check measures the f32 rounding of the oracle, not parity
+    rms = float(np.sqrt(np.mean(np.asarray(want, dtype=np.float64) ** 2)))
+    oracle.assert_close_elementwise(got, want, atol * max(1.0, rms / 64.0), rtol, what)
 
 
 # ---- c2c ------------------------------------------------------------------------------------------------
@@ -463,6 +467,25 @@ def test_impulse_and_constant(fft, dev, oracle):
     x[0::2] = 1.0
     got, _ = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size)
     assert abs(got[0] - n) < 1e-3 * n and np.max(np.abs(got[2:])) < 1e-2
+
+
+@pytest.mark.parametrize("lg", [16, 20, 21])
+def test_accuracy_against_f64(fft, dev, oracle, monkeypatch, lg):
+    """error against an f64 FFT: both four-step routes stay within a few f32 roundings (measured 1.6e-7 ... 2.4e-7; the
+    oracle, which keeps f64 twiddles and rounds its data to f32 per stage, sits at 1.0e-7 ... 1.2e-7) — 40x inside the
+    1e-5 parity tolerance"""
+    n = 1 << lg
+    x = oracle.random_complex_batch(n, 1, 0xACC0 + lg).reshape(-1)
+    exact = np.fft.fft(x.astype(np.float64).view(np.complex128)).view(np.float64)
+    ref_err = oracle.rel_l2(oracle.c2c_ref_batch(x, [n], 1, "forward", "none"), exact)
+    errs = {}
+    for fused in (0, 1):
+        monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+        got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": 1, "direction": "forward", "normalize": "none"}, x, x.size)
+        errs[route.strip()] = oracle.rel_l2(got, exact)
+    print(f"N=2^{lg}: rel_l2 vs f64: {errs}, oracle {ref_err:.3e}")
+    for route, e in errs.items():
+        assert e < 4e-7 and e < 4.0 * ref_err, (route, e, ref_err)
 
 
 def test_torch_fft_cross_check(fft, dev, oracle):
