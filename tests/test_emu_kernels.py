@@ -179,6 +179,38 @@ def test_c2r_ignores_imag_of_self_conjugate_bins(oracle):
     check(got, x, "self-conjugate bins vs signal")
 
 
+@pytest.mark.parametrize("cus,xcds,split", [(2, 2, 1), (6, 3, 1), (8, 2, 2), (6, 1, 4)])
+def test_r2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
+    """real four-step in one persistent launch (kern_xcd_real.hpp), test instance 64 x 64; unitary scale included"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    n, batch = 4096, 7
+    x = oracle.random_real_batch(n, batch, 0xD00D + cus).reshape(-1)
+    for norm in ("none", "unitary"):
+        want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm) for b in range(batch)])
+        desc = _abi.make_desc("r2c", [n], batch, "forward", norm)
+        got, route, launches = emu.run_plan(desc, x, batch * (n // 2 + 1) * 2)
+        assert route.startswith("xcd-r2c[N=64x64]") and launches == 2, route
+        check(got, want, f"xcd-r2c {norm} cus={cus} xcds={xcds} split={split}", 1e-5)
+
+
+@pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024"), (21, "1024x2048"), (22, "2048x2048")])
+def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "4")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", "2")
+    n, batch = 1 << lg, 3
+    x = oracle.random_real_batch(n, batch, 0xD100 + lg).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    desc = _abi.make_desc("r2c", [n], batch, "forward", "none")
+    got, route, launches = emu.run_plan(desc, x, batch * (n // 2 + 1) * 2)
+    assert route.startswith(f"xcd-r2c[N={label}]") and launches == 2, route
+    check(got, want, f"xcd-r2c {label}", 1e-5)
+
+
 def test_r2c_rejects_inverse_and_c2r_rejects_forward():
     for typ, direction, frag in (("r2c", "inverse", "forward"), ("c2r", "forward", "inverse")):
         desc = _abi.make_desc(typ, [16], 1, direction, "none")

@@ -278,6 +278,22 @@ def test_r2c_c2r(fft, dev, oracle, n):
     check(oracle, back, x, f"c2r(r2c) N={n}", 2e-3, 2e-3)
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("lg,batch", [(18, 70), (19, 37), (20, 35), (21, 19), (22, 18)])
+def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
+    """long power-of-two r2c on both routes: XCD-fused real four-step (one launch, more transforms than groups so that
+    the workspace slots alternate) and the half-length c2c + split route"""
+    monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+    n = 1 << lg
+    p = n // 2 + 1
+    x = oracle.random_real_batch(n, batch, 0xE100 + lg).reshape(-1)
+    for norm in ("none", "unitary"):
+        got, (route, launches) = run_plan(fft, dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": norm}, x, 2 * p * batch)
+        assert route.startswith("xcd-r2c[") == bool(fused), route
+        want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm, use_pow2=True) for b in range(batch)])
+        check(oracle, got, want, f"r2c 2^{lg} {norm} ({route.strip()})", 8e-4, 8e-4)
+
+
 def test_r2c_golden_fixtures(fft, dev, oracle, manifest):
     cases, _ = manifest
     seen = 0

@@ -11,7 +11,7 @@
 #include "kern_fftconv.hpp"
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
-#include "kern_xcd.hpp"
+#include "kern_xcd_real.hpp"
 #include "plan.hpp"
 
 namespace mi355 {
@@ -91,6 +91,16 @@ template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned
   }
   MI355_XCD_KERNEL_LIST(X)
 #undef X
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
+  if (id == cur++) {                                                                              \
+    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
+    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
+    using F = XcdFusedCfg<CA, CB>;                                                                \
+    l.launch_concurrent(fft_xcd_r2c_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
+    return true;                                                                                  \
+  }
+  MI355_XCD_R2C_KERNEL_LIST(X)
+#undef X
   (void)cur;
   return false;
 }
@@ -116,6 +126,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       const char* tb = (const char*)ptr[4];
       a.tw_a = (const cf*)(tb + s.i[4]); a.tw_b = (const cf*)(tb + s.i[5]); a.tw_lo = (const cf*)(tb + s.i[6]); a.tw_hi = (const cf*)(tb + s.i[7]);
       a.num_transforms = s.i[0]; a.N = s.i[1]; a.fs_shift = (int)s.i[2]; a.fs_lo_mask = (unsigned)s.i[3];
+      a.in_pitch = s.i[9]; a.out_pitch = s.i[10];
       a.scale = s.f[0];
       a.sticky_error = l.sticky_error_word();
       a.spin_limit = 4000000u;

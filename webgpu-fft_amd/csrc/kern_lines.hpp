@@ -185,14 +185,17 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
   }
 }
 
-template <class C, int S, bool NT = false>
+// KEEP_IN_LDS: the last stage leaves the finished lines in LDS (same layout as the exchanges) instead of storing them to
+// global memory — for kernels that post-process a whole line before it leaves the workgroup (kern_xcd_real.hpp)
+template <class C, int S, bool NT = false, bool KEEP_IN_LDS = false>
 MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile, int t, cf* lds, const cf* tw_lds, const cf* lo_lds) {
   using I = StageInfo<C, S>;
+  constexpr bool TO_GLOBAL = I::LAST && !KEEP_IN_LDS;
   int line, u; thread_map<C, S>(t, line, u);
   cf* po = nullptr;
   unsigned ls = 1, es = 1, gi = 0;
   bool live = true;
-  if constexpr (I::LAST) {
+  if constexpr (TO_GLOBAL) {
     const long long G0 = tile * C::T;
     po = a.out + tile_base<C::OUT_COL>(G0, a.out_S, a.out_outer_stride);
     ls = C::OUT_COL ? 1u : (unsigned)a.out_outer_stride;
@@ -216,7 +219,7 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
 #pragma unroll
     for (int q = 0; q < I::R; ++q) {
       const int oidx = obase_idx + q * I::NSP;
-      if constexpr (I::LAST) {
+      if constexpr (TO_GLOBAL) {
         cf r = w[q];
         if constexpr (C::TWID == TWID_FOURSTEP_OUT) {
           // e^{-2 pi i (n2 * k1)/Ntot} = HI[m >> s] * LO[m & mask],  m = n2*k1 < Ntot

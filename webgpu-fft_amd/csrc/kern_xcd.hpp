@@ -1,12 +1,12 @@
 // kern_xcd.hpp — XCD-fused four-step: both passes of an N = N1*N2 transform in ONE persistent launch, the 32
 // workgroups that share an XCD (one per CU) working on one transform at a time.
 //
-// Why (profiles/r01_xcd_fused_two_pass_prototype.log): the two-kernel route moves every point over
-// the fabric four times (32 B/point) and both passes already run at the speed of a copy with their access pattern.
-// Here pass A writes its 8 MiB intermediate into a per-XCD workspace slot that is re-used for every transform and pass B
-// of the SAME XCD reads it back a few microseconds later: whatever is still in that XCD's 4 MiB L2 (or the Infinity Cache)
-// never crosses the fabric twice.  The data-movement skeleton measured 5.6 us per 2^20-point transform against 6.6 for the
-// two-kernel route.
+// Why (profiles/r01_xcd_fused_ab.log): the two-kernel route runs the whole chip in lock-step (all CUs
+// load, then all compute, then all store, one launch pair per chunk).  Here groups of workgroups that share an L2 walk
+// the batch independently, drift out of phase with each other and keep the fabric busy in both directions; the
+// intermediate of a transform lives in a small per-group workspace slot that is re-used for every transform.
+// Measured at N = 2^20: 186 GPoints/s against 155 for the two-kernel route.  (The intermediate still crosses the fabric
+// twice — 8 MiB per transform does not survive in a 4 MiB L2 — see the PMC summary under profiles/.)
 //
 // Structure per launch (grid = one workgroup per CU, LDS-limited):
 //   registration: every workgroup reads its XCC id, takes a rank inside that XCD and waits (bounded) until all
@@ -50,7 +50,8 @@ struct XcdFusedArgs {
   const cf* tw_lo;               // four-step roots: e^{-2 pi i m/N} = HI[m >> shift] * LO[m & mask]
   const cf* tw_hi;
   long long num_transforms;
-  long long N;                   // N1 * N2
+  long long N;                   // N1 * N2 (r2c: the real length)
+  long long in_pitch, out_pitch; // complex elements between consecutive transforms (c2c: N, N; r2c: N/2, N/2 + 1)
   float scale;
   int fs_shift;
   unsigned fs_lo_mask;
@@ -108,36 +109,25 @@ MI_DEV bool xcd_wait(unsigned* counter, unsigned target, unsigned spin_limit, un
   return *s_flag != 0;
 }
 
-template <class CA, class CB>
-__global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFusedArgs f) {
-  static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
-  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL && CB::OUT_COL, "PASS_A then PASS_B");
-  MI_SMEM_DECL(smem);
-  cf* lds = reinterpret_cast<cf*>(smem);
-  constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
-  cf* tw_a = lds + DATA;
-  cf* tw_b = tw_a + CA::TW_ELEMS;
-  unsigned* s_words = reinterpret_cast<unsigned*>(tw_b + CB::TW_ELEMS);   // [0] group slot, [1] rank, [2] group size, [3] ok, [4] group index, [5] groups, [6] barrier flag
-  const int t = threadIdx.x;
-  for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
-  for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i];
-
-  // ---- registration ----
-  if (t == 0) {
+// Registration: every workgroup reads its XCC id, takes a rank inside that XCD and waits (bounded) until the whole grid has
+// registered, then derives its group from the registered counts.  s_words (LDS): [0] group slot, [1] rank, [2] group size,
+// [3] ok, [4] group index, [5] groups, [6] barrier flag.  Returns false on timeout (sticky error bit 0 raised).
+MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, unsigned* sticky, unsigned* s_words) {
+  if (threadIdx.x == 0) {
     const unsigned x = MI_XCC_ID() & 15u;
-    const unsigned r = MI_ATOMIC_ADD_U32(&f.ctl->reg_xcd[x], 1u);
-    MI_ATOMIC_ADD_U32(&f.ctl->reg_total, 1u);
+    const unsigned r = MI_ATOMIC_ADD_U32(&ctl->reg_xcd[x], 1u);
+    MI_ATOMIC_ADD_U32(&ctl->reg_total, 1u);
     unsigned ok = 0;
-    for (unsigned it = 0; it < f.spin_limit; ++it) {
-      if (MI_ATOMIC_LOAD_U32(&f.ctl->reg_total) >= gridDim.x) { ok = 1; break; }
+    for (unsigned it = 0; it < spin_limit; ++it) {
+      if (MI_ATOMIC_LOAD_U32(&ctl->reg_total) >= gridDim.x) { ok = 1; break; }
       MI_SLEEP();
     }
     // an XCD's workgroups may be split into up to 4 groups by rank (each with its own workspace slots and barrier counter):
     // smaller groups run out of phase with each other inside one XCD at the price of sharing its L2
-    const unsigned split = f.split ? f.split : 1u;
+    const unsigned split = split_arg ? split_arg : 1u;
     unsigned groups = 0, gi = 0, mine = 0, sub = 0, gsz = 0;
     for (unsigned k = 0; k < 16; ++k) {
-      const unsigned cnt = MI_ATOMIC_LOAD_U32(&f.ctl->reg_xcd[k]);
+      const unsigned cnt = MI_ATOMIC_LOAD_U32(&ctl->reg_xcd[k]);
       if (!cnt) continue;
       const unsigned per = (cnt + split - 1u) / split, nsub = (cnt + per - 1u) / per;
       if (k == x) {
@@ -148,10 +138,34 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       groups += nsub;
     }
     s_words[0] = x * split + sub; s_words[1] = mine; s_words[2] = gsz; s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
-    if (!ok) MI_ATOMIC_OR_U32(f.sticky_error, 1u);
+    if (!ok) MI_ATOMIC_OR_U32(sticky, 1u);
   }
   __syncthreads();
-  if (!s_words[3]) return;
+  return s_words[3] != 0;
+}
+
+// both passes use the same radix plan: one copy of the stage tables serves both
+template <class CA, class CB> struct XcdTables {
+  static constexpr bool SHARED = CA::N == CB::N && CA::R0 == CB::R0 && CA::R1 == CB::R1 && CA::R2 == CB::R2;
+  static constexpr int ELEMS = CA::TW_ELEMS + (SHARED ? 0 : CB::TW_ELEMS);
+};
+
+template <class CA, class CB>
+__global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFusedArgs f) {
+  static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
+  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL && CB::OUT_COL, "PASS_A then PASS_B");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
+  using TB = XcdTables<CA, CB>;
+  cf* tw_a = lds + DATA;
+  cf* tw_b = TB::SHARED ? tw_a : tw_a + CA::TW_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw_a + TB::ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
+  if constexpr (!TB::SHARED) { for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i]; }
+
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
   const long long N1 = CA::N, N2 = CB::N;
@@ -169,7 +183,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
     cf* const W = W0 + (size_t)(k & 1u) * (size_t)f.N;
     // ---- phase A: column FFTs of transform tr into this XCD's workspace slot ----
-    aa.in = f.in + tr * f.N; aa.out = W;
+    aa.in = f.in + tr * f.in_pitch; aa.out = W;
     for (long long tile = rank; tile < aa.num_tiles; tile += gsize) {
       cf v[CA::E];
       stage_read<CA, 0, XCD_NT>(v, aa, tile, t, lds);       // x streams past the L2
@@ -191,7 +205,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
     xcd_arrive(&f.ctl->bar[gslot][0]);
     if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     // ---- phase B: four-step roots on load, row FFTs, transposed store to the output ----
-    ab.in = W; ab.out = f.out + tr * f.N;
+    ab.in = W; ab.out = f.out + tr * f.out_pitch;
     for (long long tile = rank; tile < ab.num_tiles; tile += gsize) {
       cf v[CB::E];
       stage_read<CB, 0>(v, ab, tile, t, lds);
@@ -219,7 +233,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
 
 template <class CA, class CB> struct XcdFusedCfg {
   static constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
-  static constexpr int LDS_BYTES = (DATA + CA::TW_ELEMS + CB::TW_ELEMS) * 8 + 64;
+  static constexpr int LDS_BYTES = (DATA + XcdTables<CA, CB>::ELEMS) * 8 + 64;
   static constexpr int THREADS = CA::THREADS;
   static_assert(LDS_BYTES <= 160 * 1024, "fused tile does not fit LDS");
 };

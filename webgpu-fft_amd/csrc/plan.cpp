@@ -83,17 +83,25 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
   static const std::vector<XcdKernelMeta> reg = [] {
     std::vector<XcdKernelMeta> r;
     int id = 0;
-#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
-  for (int inv = 0; inv < 2; ++inv) {                                                                     \
-    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, inv != 0, false, 0);           \
-    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, true, false, inv != 0, 0);          \
-    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, inv != 0, ma.threads, 0};           \
+#define XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, INV, REAL)                                       \
+  {                                                                                                       \
+    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, INV, false, 0);                \
+    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, true, false, INV, 0);               \
+    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, INV, ma.threads, 0, REAL};          \
     const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
-    m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + mb.tw_elems) * 8 + 64;                             \
+    const bool shared = N1 == N2 && A0 == B0 && A1 == B1 && A2 == B2;                                     \
+    m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + (shared ? 0 : mb.tw_elems)) * 8 + 64;              \
     r.push_back(m);                                                                                       \
   }
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, false)                                          \
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, true, false)
     MI355_XCD_KERNEL_LIST(X)
 #undef X
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, true)
+    MI355_XCD_R2C_KERNEL_LIST(X)
+#undef X
+#undef XCD_META
     return r;
   }();
   return reg;
@@ -201,6 +209,37 @@ struct Builder {
 
   // batched 1-D FFT along an axis of a dense array: `lines` = S*outer lines of length N, element stride S.
   //   src/dst may be the same location.  inverse => e^{+...}.  scale fused into the last launch.
+  // XCD-fused r2c of `lines` dense real lines of length N into packed spectra of N/2+1 bins; false if no instance applies
+  bool emit_xcd_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale) {
+    if (opt.force_generic || !opt.xcd_fused || opt.only_pass || N < 4096 || (N & (N - 1))) return false;
+    const int lgf = lg2(N);
+    const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
+    const XcdKernelMeta* xm = nullptr;
+    for (const auto& m : xcd_kernel_registry()) if (m.real && m.N1 == F1 && m.N2 == F2) xm = &m;
+    if (!xm || (N <= 8192 && opt.xcd_fused != 2)) return false;
+    const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+    const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
+    const int64_t split = opt.xcd_split > 0 ? opt.xcd_split : 1;
+    const int64_t wsize = (F1 / 2 + 1) * F2;                       // rows 0..N1/2 of the intermediate
+    const PtrRef wslots = alloc_work((uint64_t)(32 * split) * wsize * 8);
+    const PtrRef ctl = alloc_work(8192);
+    const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
+    std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
+    for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
+    for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
+    const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
+    Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 2048; z.grid = 1;
+    Step& st = push(ST_XCD_FUSED);
+    st.variant = xm->id;
+    st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+    st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N / 2; st.i[10] = N / 2 + 1;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split;
+    st.f[0] = scale;
+    st.grid = (unsigned)opt.compute_units;
+    ir.route += "xcd-r2c[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    return true;
+  }
+
   int emit_axis(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, std::string& err) {
     const int64_t lines = S * outer;
     // work buffers taken inside one axis transform are temporaries: released on every exit
@@ -245,7 +284,7 @@ struct Builder {
       const int lgf = lg2(N);
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
-      for (const auto& m : xcd_kernel_registry()) if (m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
+      for (const auto& m : xcd_kernel_registry()) if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2)) {
         const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
         const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
@@ -260,7 +299,7 @@ struct Builder {
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
-        st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023;
+        st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023; st.i[9] = N; st.i[10] = N;
         st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split;
         st.f[0] = scale;
         st.grid = (unsigned)opt.compute_units;     // one workgroup per CU (LDS-limited), all co-resident
@@ -660,7 +699,9 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     b.ir.route += "gather ";
   }
   if (d.output.strided) out = b.alloc_work((uint64_t)pn * d.batch * 8);
-  if (N % 2 == 0) {
+  if (b.emit_xcd_r2c(in, out, N, lines, scale)) {
+    // one persistent launch: real four-step (kern_xcd_real.hpp)
+  } else if (N % 2 == 0) {
     const int64_t H = N / 2;
     PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
     // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]

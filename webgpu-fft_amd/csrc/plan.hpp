@@ -43,8 +43,12 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
 // emulation tests.)  N = 2^18, 2^19, 2^20, 2^21 (the c2c half of r2c/c2r N = 2^22).
 #define MI355_XCD_KERNEL_LIST(X) \
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
-  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
-struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; };
+  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8) X(2048, 32, 32, 2, 8, 2048, 32, 32, 2, 8)
+// r2c variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; forward only.  2^12 (test instance), 2^18 .. 2^22
+#define MI355_XCD_R2C_KERNEL_LIST(X) \
+  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
+  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8) X(2048, 32, 32, 2, 8, 2048, 32, 32, 2, 8)
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; bool real; };
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
