@@ -179,13 +179,14 @@ def test_c2r_ignores_imag_of_self_conjugate_bins(oracle):
     check(got, x, "self-conjugate bins vs signal")
 
 
-@pytest.mark.parametrize("cus,xcds,split", [(2, 2, 1), (6, 3, 1), (8, 2, 2), (6, 1, 4)])
-def test_r2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
+@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (6, 3, 1, 1), (8, 2, 2, 2), (6, 1, 4, 1), (9, 1, 8, 2)])
+def test_r2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     """real four-step in one persistent launch (kern_xcd_real.hpp), test instance 64 x 64; unitary scale included"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
     n, batch = 4096, 7
     x = oracle.random_real_batch(n, batch, 0xD00D + cus).reshape(-1)
     for norm in ("none", "unitary"):
@@ -196,7 +197,7 @@ def test_r2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
         check(got, want, f"xcd-r2c {norm} cus={cus} xcds={xcds} split={split}", 1e-5)
 
 
-@pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024"), (21, "1024x2048"), (22, "2048x2048")])
+@pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024"), (21, "1024x2048")])
 def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_CUS", "4")
@@ -286,14 +287,15 @@ def test_r2c_c2r_whdcn_lanes(oracle):
     assert float(np.max(np.abs(back - wantr))) < 2e-6
 
 
-@pytest.mark.parametrize("cus,xcds,split", [(2, 2, 1), (4, 2, 1), (6, 3, 1), (3, 1, 1), (8, 2, 2), (8, 1, 4), (6, 1, 4)])
-def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split):
+@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (4, 2, 1, 2), (6, 3, 1, 1), (3, 1, 1, 2), (8, 2, 2, 2), (8, 1, 4, 1), (6, 1, 4, 2), (9, 1, 8, 2), (5, 1, 0, 2)])
+def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     """both passes in one persistent launch; workgroups grouped by (emulated) XCC id synchronise through global
     counters: blocks run concurrently under emulation.  N = 64 x 64 is the test instance of the kernel template."""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
     n, batch = 4096, 5
     x = oracle.random_complex_batch(n, batch, 0xF00D + cus).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):

@@ -36,7 +36,7 @@ constexpr bool XCD_NT = MI355_XCD_NT != 0;   // nontemporal x loads / output sto
 struct XcdCtl {                  // zeroed by a memset step before every launch
   unsigned reg_total;
   unsigned reg_xcd[16];
-  unsigned bar[64][16];          // one 64-byte line per group (XCC id x split)
+  unsigned bar[128][16];         // one 64-byte line per group (XCC id x split): [0] A->B barrier, [1] B->A barrier (one-slot mode)
 };
 
 struct XcdFusedArgs {
@@ -56,7 +56,8 @@ struct XcdFusedArgs {
   int fs_shift;
   unsigned fs_lo_mask;
   unsigned spin_limit;           // polls before a wait gives up
-  unsigned split;                // groups per XCD (1, 2 or 4): the workgroups of an XCD are divided by rank
+  unsigned split;                // groups per XCD (1..8): the workgroups of an XCD are divided by rank
+  unsigned slots;                // workspace slots per group: 2 (one barrier per transform) or 1 (two barriers, half the footprint)
 };
 
 // roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by
@@ -122,7 +123,7 @@ MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, u
       if (MI_ATOMIC_LOAD_U32(&ctl->reg_total) >= gridDim.x) { ok = 1; break; }
       MI_SLEEP();
     }
-    // an XCD's workgroups may be split into up to 4 groups by rank (each with its own workspace slots and barrier counter):
+    // an XCD's workgroups may be split into up to 8 groups by rank (each with its own workspace slots and barrier counter):
     // smaller groups run out of phase with each other inside one XCD at the price of sharing its L2
     const unsigned split = split_arg ? split_arg : 1u;
     unsigned groups = 0, gi = 0, mine = 0, sub = 0, gsz = 0;
@@ -142,6 +143,23 @@ MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, u
   }
   __syncthreads();
   return s_words[3] != 0;
+}
+
+// Tile order inside a group.  Tiles narrower than 16 lines move 64-byte segments; a workgroup then takes PAIRS of adjacent
+// tiles back to back (and leaves their accesses temporal) so that the two halves of every 128-byte line meet in the L2
+// within a few microseconds instead of crossing the fabric as partial lines.
+#ifndef MI355_XCD_PAIR
+#define MI355_XCD_PAIR 1
+#endif
+// Whether the paired tiles keep nontemporal accesses is measured per kernel (profiles/r01_xcd_fused_ab.log): the c2c kernel
+// is faster with them (147.6 vs 141.1 GPoints/s at N = 2^21), the r2c kernel without (222 vs 202 at N = 2^21).
+template <class Cfg, bool PAIR_NT = true> struct PairOf {
+  static constexpr int C = (MI355_XCD_PAIR && Cfg::T * 8 < 128) ? 128 / (Cfg::T * 8) : 1;
+  static constexpr bool NT = XCD_NT && (C == 1 || PAIR_NT);
+};
+template <class C> MI_DEV long long xcd_tile(long long i, unsigned rank, unsigned gsize) {
+  constexpr int P = PairOf<C>::C;
+  return ((i / P) * (long long)gsize + rank) * P + (i % P);
 }
 
 // both passes use the same radix plan: one copy of the stage tables serves both
@@ -178,15 +196,19 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one group barrier per transform.
   // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, loses more than it gains: 150 vs 165
   // GPoints/s at N = 2^20.)
-  cf* const W0 = f.wslots + (size_t)(2u * gslot) * (size_t)f.N;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
-    cf* const W = W0 + (size_t)(k & 1u) * (size_t)f.N;
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)f.N;
     // ---- phase A: column FFTs of transform tr into this XCD's workspace slot ----
     aa.in = f.in + tr * f.in_pitch; aa.out = W;
-    for (long long tile = rank; tile < aa.num_tiles; tile += gsize) {
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CA>(i, rank, gsize);
+      if (tile - (i % PairOf<CA>::C) >= aa.num_tiles) break;
+      if (tile >= aa.num_tiles) continue;
       cf v[CA::E];
-      stage_read<CA, 0, XCD_NT>(v, aa, tile, t, lds);       // x streams past the L2
+      stage_read<CA, 0, PairOf<CA>::NT>(v, aa, tile, t, lds);       // x streams past the L2
       stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
       if constexpr (CA::NSTAGES >= 2) {
         __syncthreads();
@@ -206,27 +228,34 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
     if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     // ---- phase B: four-step roots on load, row FFTs, transposed store to the output ----
     ab.in = W; ab.out = f.out + tr * f.out_pitch;
-    for (long long tile = rank; tile < ab.num_tiles; tile += gsize) {
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CB>(i, rank, gsize);
+      if (tile - (i % PairOf<CB>::C) >= ab.num_tiles) break;
+      if (tile >= ab.num_tiles) continue;
       cf v[CB::E];
       stage_read<CB, 0>(v, ab, tile, t, lds);
       {
         int line, u; thread_map<CB, 0>(t, line, u);
         fourstep_apply_chain<CB>(v, f, (unsigned)(tile * CB::T + line), u);
       }
-      stage_compute_write<CB, 0, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);
+      stage_compute_write<CB, 0, PairOf<CB>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
       if constexpr (CB::NSTAGES >= 2) {
         __syncthreads();
         stage_read<CB, 1>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 1, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);   // output streams past the L2
+        stage_compute_write<CB, 1, PairOf<CB>::NT>(v, ab, tile, t, lds, tw_b, nullptr);   // output streams past the L2
       }
       if constexpr (CB::NSTAGES == 3) {
         __syncthreads();
         stage_read<CB, 2>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 2, XCD_NT>(v, ab, tile, t, lds, tw_b, nullptr);
+        stage_compute_write<CB, 2, PairOf<CB>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
       }
       __syncthreads();
+    }
+    if (!two_slots) {   // everyone has read the slot before phase A of the next transform overwrites it
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     }
   }
 }

@@ -46,15 +46,19 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
   aa.in_S = N2 / 2; aa.in_outer_stride = f.N / 2; aa.out_S = N2 / 2; aa.out_outer_stride = f.N / 2; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = (ROWS + CB::T - 1) / CB::T; ab.num_lines = ROWS;
   ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
-  cf* const W0 = f.wslots + (size_t)(2u * gslot) * (size_t)wsize;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)wsize;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
-    cf* const W = W0 + (size_t)(k & 1u) * (size_t)wsize;
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)wsize;
     // ---- phase A: pairs of real columns as complex columns, FFT, separation, rows 0..N1/2 of W ----
     aa.in = f.in + tr * f.in_pitch; aa.out = W;
-    for (long long tile = rank; tile < aa.num_tiles; tile += gsize) {
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CA>(i, rank, gsize);
+      if (tile - (i % PairOf<CA>::C) >= aa.num_tiles) break;
+      if (tile >= aa.num_tiles) continue;
       cf v[CA::E];
-      stage_read<CA, 0, XCD_NT>(v, aa, tile, t, lds);
+      stage_read<CA, 0, PairOf<CA, false>::NT>(v, aa, tile, t, lds);
       stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
       __syncthreads();
       stage_read<CA, 1>(v, aa, tile, t, lds);
@@ -86,7 +90,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
     // ---- phase B: rows 0..N1/2, four-step roots, row FFT, transposed store with the Hermitian mirror ----
     ab.in = W;
     cf* const po = f.out + tr * f.out_pitch;
-    for (long long tile = rank; tile < ab.num_tiles; tile += gsize) {
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CB>(i, rank, gsize);
+      if (tile - (i % PairOf<CB>::C) >= ab.num_tiles) break;
+      if (tile >= ab.num_tiles) continue;
       cf v[CB::E];
       stage_read<CB, 0>(v, ab, tile, t, lds);
       {
@@ -128,17 +135,21 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
             if (ab.scale != 1.0f) r = r * ab.scale;
             const int uni = (b * CB::TPL + q * I::NSP) * N1;     // uniform part of k = k1 + N1*k2, k2 = j + q*(N2/R)
             if (q < I::R / 2) {
-              if (live) st_stream<XCD_NT>(po + (uni + voff), r);
+              if (live) st_stream<PairOf<CB, false>::NT>(po + (uni + voff), r);
             } else {
               // k > N/2 (or = N/2 for k1 = 0, k2 = N2/2, which is its own mirror and stays unconjugated)
               const bool nyq = k1 == 0 && q == I::R / 2 && j == 0;
               cf m; m.x = r.x; m.y = nyq ? r.y : -r.y;
-              if (live && (!edge || nyq)) st_stream<XCD_NT>(po + ((int)f.N - uni - voff), m);
+              if (live && (!edge || nyq)) st_stream<PairOf<CB, false>::NT>(po + ((int)f.N - uni - voff), m);
             }
           }
         }
       }
       __syncthreads();
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     }
   }
 }

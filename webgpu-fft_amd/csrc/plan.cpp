@@ -113,7 +113,9 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
-  if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 1 && v <= 4) o.xcd_split = v; }
+  if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 8) o.xcd_split = v; }
+  if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
   return o;
 }
 
@@ -209,9 +211,18 @@ struct Builder {
 
   // batched 1-D FFT along an axis of a dense array: `lines` = S*outer lines of length N, element stride S.
   //   src/dst may be the same location.  inverse => e^{+...}.  scale fused into the last launch.
+  // groups per XCD for the fused kernels.  Measured (profiles/r01_xcd_fused_ab.log): more, smaller groups are better as long
+  // as all their workspace slots together stay within the 256 MiB Infinity Cache (8 XCDs x split x slots x slot bytes)
+  int64_t xcd_split_for(uint64_t slot_bytes) const {
+    if (opt.xcd_split > 0) return opt.xcd_split;
+    int64_t split = 8;
+    while (split > 1 && (uint64_t)(8 * opt.xcd_slots * split) * slot_bytes > ((uint64_t)320 << 20)) split >>= 1;   // (r2c slots are N/2 + N2 points: a little over a power of two)
+    return split;
+  }
+
   // XCD-fused r2c of `lines` dense real lines of length N into packed spectra of N/2+1 bins; false if no instance applies
   bool emit_xcd_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale) {
-    if (opt.force_generic || !opt.xcd_fused || opt.only_pass || N < 4096 || (N & (N - 1))) return false;
+    if (opt.force_generic || !opt.xcd_fused || !opt.xcd_r2c || opt.only_pass || N < 4096 || (N & (N - 1))) return false;
     const int lgf = lg2(N);
     const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
     const XcdKernelMeta* xm = nullptr;
@@ -219,21 +230,21 @@ struct Builder {
     if (!xm || (N <= 8192 && opt.xcd_fused != 2)) return false;
     const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
-    const int64_t split = opt.xcd_split > 0 ? opt.xcd_split : 1;
     const int64_t wsize = (F1 / 2 + 1) * F2;                       // rows 0..N1/2 of the intermediate
-    const PtrRef wslots = alloc_work((uint64_t)(32 * split) * wsize * 8);
-    const PtrRef ctl = alloc_work(8192);
+    const int64_t split = xcd_split_for((uint64_t)wsize * 8);
+    const PtrRef wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * wsize * 8);
+    const PtrRef ctl = alloc_work(16384);
     const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
     std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
     for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
     const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
-    Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 2048; z.grid = 1;
+    Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1;
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
     st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
     st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N / 2; st.i[10] = N / 2 + 1;
-    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = opt.xcd_slots;
     st.f[0] = scale;
     st.grid = (unsigned)opt.compute_units;
     ir.route += "xcd-r2c[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
@@ -288,19 +299,19 @@ struct Builder {
       if (xm && (N > 4096 || opt.xcd_fused == 2)) {
         const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
         const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
-        const int64_t split = opt.xcd_split > 0 ? opt.xcd_split : 1;
-        const PtrRef wslots = alloc_work((uint64_t)(32 * split) * N * 8);   // two slots per group, `split` groups per XCC id (16 ids)
-        const PtrRef ctl = alloc_work(8192);
+        const int64_t split = xcd_split_for((uint64_t)N * 8);
+        const PtrRef wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);   // slots per group x `split` groups per XCC id (16 ids)
+        const PtrRef ctl = alloc_work(16384);
         std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, N >> 10));
         for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
         for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
         const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
-        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 2048; z.grid = 1;
+        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1;
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
         st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023; st.i[9] = N; st.i[10] = N;
-        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split;
+        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = opt.xcd_slots;
         st.f[0] = scale;
         st.grid = (unsigned)opt.compute_units;     // one workgroup per CU (LDS-limited), all co-resident
         ir.route += "xcd-fused[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";

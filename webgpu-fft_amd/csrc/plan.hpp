@@ -44,10 +44,12 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
 #define MI355_XCD_KERNEL_LIST(X) \
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8) X(2048, 32, 32, 2, 8, 2048, 32, 32, 2, 8)
-// r2c variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; forward only.  2^12 (test instance), 2^18 .. 2^22
+// r2c variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; forward only.  2^12 (test instance), 2^18 .. 2^21.
+// (2^22 = 2048 x 2048 with 8-wide tiles on both passes was built and measured slower than the half-length route over the
+// fused c2c kernel — 153-163 vs 183 G real points/s — and is not instantiated.)
 #define MI355_XCD_R2C_KERNEL_LIST(X) \
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
-  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8) X(2048, 32, 32, 2, 8, 2048, 32, 32, 2, 8)
+  X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
 struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; bool real; };
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
@@ -92,7 +94,9 @@ struct PlannerOptions {
   int compute_units = 256;
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
-  int xcd_split = 2;                   // groups per XCD in the fused kernel (1..4); 2 measured best (profiles/r01_xcd_fused_ab.log)
+  int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
+  int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
+  int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };
 PlannerOptions planner_options_from_env();
