@@ -237,9 +237,11 @@ def main():
         step_dev_s = dev_max / args.steps
         achieved = bytes_per_point * float(n) * batch / step_dev_s / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
-        fused = "xcd-fused" in route
+        fused = ("xcd-fused" in route or "xcd-r2c" in route) and launches == 2
         if fused:
             dominant, dominant_launches = "fft_xcd_fused_kernel (pass A + XCD barrier + pass B in one persistent launch)", 1
+        elif "xcd-fused" in route:
+            dominant, dominant_launches = "fft_xcd_fused_kernel, then " + route.split("]")[-1].strip() + " kernel", launches - 1
         elif "two-pass" in route:
             dominant, dominant_launches = "fft_lines_kernel (pass A + pass B per chunk)", launches
         else:
