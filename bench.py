@@ -159,11 +159,12 @@ def main():
 
     if args.workload not in WORKLOADS:   # probes: c2c_2pL_bB / r2c_2pL_bB (never the headline line)
         import re
-        m = re.fullmatch(r"(c2c|r2c)_2p(\d+)_b(\d+)", args.workload)
+        m = re.fullmatch(r"(c2c|r2c)_(2p|n)(\d+)_b(\d+)", args.workload)
         if not m:
             raise SystemExit(f"unknown workload {args.workload}")
-        WORKLOADS[args.workload] = (m.group(1), 1 << int(m.group(2)), int(m.group(3)), 16 if m.group(1) == "c2c" else 8,
-                                    f"1D {m.group(1)} N=2^{m.group(2)} batch={m.group(3)} (probe; NOT a BASELINE config)")
+        nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
+        WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) == "c2c" else 8,
+                                    f"1D {m.group(1)} N={nn} batch={m.group(4)} (probe; NOT a BASELINE config)")
     typ, n, batch, bytes_per_point, desc = WORKLOADS[args.workload]
     dev = mi355fft.Device(local_rank, use_graph=False if args.no_graph else "auto")
     info = dev.info()

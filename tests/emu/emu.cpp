@@ -130,6 +130,7 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   if (const char* e = std::getenv("MI355_EMU_XCD_FUSED")) opt.xcd_fused = std::atoi(e); else opt.xcd_fused = 0;
   if (const char* e = std::getenv("MI355_EMU_XCD_SPLIT")) opt.xcd_split = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_SLOTS")) opt.xcd_slots = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_MIXED_LINES")) opt.mixed_lines = std::atoi(e);
   emu::g_xcds = std::getenv("MI355_EMU_XCDS") ? (unsigned)std::atoi(std::getenv("MI355_EMU_XCDS")) : 2u;
   PlanIR ir;
   std::string e;

@@ -75,15 +75,34 @@ def test_c2c_two_pass_2p22(oracle):
         check(got, oracle.c2c_ref_batch(x, [n], 1, direction, "none"), f"two-pass 2^22 {direction}")
 
 
-@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 24, 96, 105, 210, 1001, 8 * 13 * 11])
-def test_c2c_generic_mixed_radix(oracle, n):
-    batch = 2
+@pytest.mark.parametrize("mixed", [0, 1])
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 24, 96, 105, 210, 1001, 8 * 13 * 11, 2187, 3 * 1024, 4095])
+def test_c2c_generic_mixed_radix(oracle, monkeypatch, n, mixed):
+    """mixed-radix lengths on the one-launch LDS line kernel (kern_mixed.hpp) and on the global-memory stage route"""
+    monkeypatch.setenv("MI355_EMU_MIXED_LINES", str(mixed))
+    batch = 5 if n < 200 else 2
     x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
-    for direction in ("forward", "inverse"):
-        desc = _abi.make_desc("c2c", [n], batch, direction, "none")
-        got, route, _ = emu.run_plan(desc, x, x.size)
-        assert route.startswith("stages[")
-        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"generic N={n} {direction}", 2e-6 if n < 1000 else 1e-5)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        if mixed and n not in (3, 5, 7, 11, 13):
+            assert route.startswith("mixed-lines[") and launches == 1, route
+        else:
+            assert route.startswith("stages[")
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 2e-6 if n < 1000 else 1e-5)
+
+
+@pytest.mark.parametrize("shape,expect", [([96, 105], 2), ([24, 25, 27], 3), ([6, 10, 4], 2), ([1000, 3], 1)])
+def test_c2c_nd_mixed_radix_lines(oracle, shape, expect):
+    """N-D shapes of the reference's suites (complete.suite.js:876-913): every axis, contiguous or strided, in one launch"""
+    batch = 2
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0xC500 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", shape, batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.count("mixed-lines[") == expect, route   # power-of-two and single-radix axes keep their routes
+        check(got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} {route}", 1e-5)
 
 
 def test_c2c_generic_route_matches_lines_route(oracle):

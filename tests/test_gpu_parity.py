@@ -168,14 +168,32 @@ def test_c2c_large_golden_samples(fft, dev, oracle, manifest):
         assert abs(float(np.sum(got.astype(np.float64) ** 2)) / c["out_sumsq"] - 1.0) < 1e-5, name
 
 
-@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 96, 105, 210, 1001, 1144, 3 * 4096])
-def test_c2c_mixed_radix(fft, dev, oracle, n):
-    batch = 4
+@pytest.mark.parametrize("mixed", [0, 1])
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 96, 105, 210, 1000, 1001, 1144, 2187, 3000, 4095, 3 * 4096])
+def test_c2c_mixed_radix(fft, dev, oracle, monkeypatch, n, mixed):
+    """mixed-radix lengths: the one-launch LDS line kernel (N <= 4096, >= 2 stages) and the global-memory stage route"""
+    monkeypatch.setenv("MI355FFT_MIXED_LINES", str(mixed))
+    batch = 300 if n < 200 else 37            # several tiles per workgroup, ragged last tile
     x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
-    for direction in ("forward", "inverse"):
-        got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
-        assert route.startswith("stages[")
-        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"generic N={n} {direction}", 3e-3, 3e-3)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        if mixed and n <= 4096 and n not in (3, 5, 7, 11, 13):
+            assert route.startswith("mixed-lines[") and launches == 1, route
+        else:
+            assert route.startswith("stages["), route
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 3e-3, 3e-3)
+
+
+@pytest.mark.parametrize("shape", [[96, 105], [24, 25, 27], [1000, 3, 5]])
+def test_c2c_nd_mixed_radix(fft, dev, oracle, shape):
+    """the reference's N-D mixed-radix shapes (complete.suite.js:876-913), every axis a single launch"""
+    batch = 3
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0xC500 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": shape, "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert launches == len(shape), route
+        check(oracle, got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} {route}", 3e-3, 3e-3)
 
 
 @pytest.mark.parametrize("n", [17, 29, 34, 97, 2039, 100003])

@@ -11,6 +11,7 @@
 #include "kern_fftconv.hpp"
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
+#include "kern_mixed.hpp"
 #include "kern_xcd_real.hpp"
 #include "plan.hpp"
 
@@ -142,6 +143,16 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.scale = s.f[0];
       const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
       return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);
+    }
+    case ST_LINES_MIXED: {
+      MixedArgs a{};
+      a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2];
+      a.lines = s.i[0]; a.N = (int)s.i[1]; a.S = s.i[2]; a.T = (int)s.i[3]; a.nst = (int)s.i[4];
+      a.swap_in = a.swap_out = (int)s.i[5];
+      a.scale = s.f[0];
+      for (int k = 0; k < a.nst; ++k) { a.radix[k] = (int)(s.i[8 + k] >> 32); a.tw_off[k] = (int)(s.i[8 + k] & 0xffffffff); }
+      l.launch(fft_lines_mixed_kernel, s.grid, 256u, (unsigned)MIXED_LDS_BYTES, a);
+      return true;
     }
     case ST_STAGE: {
       StageArgs a{};

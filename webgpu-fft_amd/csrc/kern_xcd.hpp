@@ -29,6 +29,13 @@
 #define MI355_XCD_NT 1   /* same-box A/B with two groups per XCD: 185-188 GPoints/s on, 175-182 off (profiles/r01_xcd_fused_ab.log) */
 #endif
 
+#ifndef MI355_XCD_W_NT_ST
+#define MI355_XCD_W_NT_ST 0   /* experiment: nontemporal stores of the intermediate */
+#endif
+#ifndef MI355_XCD_W_NT_LD
+#define MI355_XCD_W_NT_LD 0   /* experiment: nontemporal loads of the intermediate */
+#endif
+
 namespace mi355 {
 
 constexpr bool XCD_NT = MI355_XCD_NT != 0;   // nontemporal x loads / output stores in the fused kernel
@@ -214,13 +221,13 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
         __syncthreads();
         stage_read<CA, 1>(v, aa, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CA, 1>(v, aa, tile, t, lds, tw_a, nullptr);
+        stage_compute_write<CA, 1, MI355_XCD_W_NT_ST != 0>(v, aa, tile, t, lds, tw_a, nullptr);
       }
       if constexpr (CA::NSTAGES == 3) {
         __syncthreads();
         stage_read<CA, 2>(v, aa, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CA, 2>(v, aa, tile, t, lds, tw_a, nullptr);
+        stage_compute_write<CA, 2, MI355_XCD_W_NT_ST != 0>(v, aa, tile, t, lds, tw_a, nullptr);
       }
       __syncthreads();   // LDS is re-used by the next tile
     }
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       if (tile - (i % PairOf<CB>::C) >= ab.num_tiles) break;
       if (tile >= ab.num_tiles) continue;
       cf v[CB::E];
-      stage_read<CB, 0>(v, ab, tile, t, lds);
+      stage_read<CB, 0, MI355_XCD_W_NT_LD != 0>(v, ab, tile, t, lds);
       {
         int line, u; thread_map<CB, 0>(t, line, u);
         fourstep_apply_chain<CB>(v, f, (unsigned)(tile * CB::T + line), u);

@@ -111,6 +111,7 @@ PlannerOptions planner_options_from_env() {
   PlannerOptions o;
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 8) o.xcd_split = v; }
@@ -364,6 +365,30 @@ struct Builder {
     const std::vector<int> radices = factorize_radices(N);
     if (radices.empty()) return emit_bluestein(src, dst, N, S, outer, inverse, scale, err);
     const int ns = (int)radices.size();
+    if (opt.mixed_lines && !opt.force_generic && ns >= 2 && ns <= 12 && N <= 4096) {
+      // all stages in one launch, T lines per workgroup in LDS (kern_mixed.hpp)
+      std::vector<float2h> t;
+      Step& st = push(ST_LINES_MIXED);
+      int64_t nsp = 1;
+      for (int s = 0; s < ns; ++s) {
+        const int R = radices[s];
+        st.i[8 + s] = ((int64_t)R << 32) | (int64_t)t.size();       // radix, table offset (elements)
+        const size_t off = t.size();
+        t.resize(off + (size_t)(R * nsp));
+        for (int q = 0; q < R; ++q) for (int64_t k = 0; k < nsp; ++k) t[off + (size_t)(q * nsp + k)] = root_of_unity(q * k, nsp * R);
+        nsp *= R;
+      }
+      int64_t T = 4096 / N;                                            // two LDS buffers of T*N points in 64 KB
+      T = std::max<int64_t>(1, std::min<int64_t>(T, 64));
+      st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
+      st.i[0] = lines; st.i[1] = N; st.i[2] = S; st.i[3] = T; st.i[4] = ns;
+      st.i[5] = inverse ? 1 : 0;
+      st.f[0] = scale;
+      const int64_t tiles = (lines + T - 1) / T;
+      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)opt.compute_units * 2));
+      ir.route += "mixed-lines[N=" + std::to_string(N) + ",S=" + std::to_string(S) + ",T=" + std::to_string(T) + ",n=" + std::to_string(ns) + "] ";
+      return MI355FFT_OK;
+    }
     PtrRef w0, w1;
     if (ns >= 2) w0 = alloc_work((uint64_t)lines * N * 8);
     if (ns >= 3) w1 = alloc_work((uint64_t)lines * N * 8);

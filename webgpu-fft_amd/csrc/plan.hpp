@@ -66,7 +66,7 @@ struct PtrRef {
 
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
-  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED
 };
 
 // One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).
@@ -74,7 +74,7 @@ struct Step {
   StepKind kind;
   int variant = 0;           // ST_LINES: registry id; ST_STAGE: radix
   PtrRef p[5];               // kind-specific pointer slots
-  int64_t i[12] = {0};     // kind-specific integers
+  int64_t i[20] = {0};     // kind-specific integers
   float f[2] = {1.0f, 1.0f}; // kind-specific floats
   int64_t shape[8] = {0}, sa[8] = {0}, sb[8] = {0};  // ST_GATHER / ST_SCATTER
   unsigned grid = 1;
@@ -97,6 +97,7 @@ struct PlannerOptions {
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
+  int mixed_lines = 1;                 // mixed-radix lengths <= 4096: one LDS line kernel instead of one global pass per radix
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };
 PlannerOptions planner_options_from_env();
