@@ -150,8 +150,17 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.lines = s.i[0]; a.N = (int)s.i[1]; a.S = s.i[2]; a.T = (int)s.i[3]; a.nst = (int)s.i[4];
       a.swap_in = a.swap_out = (int)s.i[5];
       a.scale = s.f[0];
-      for (int k = 0; k < a.nst; ++k) { a.radix[k] = (int)(s.i[8 + k] >> 32); a.tw_off[k] = (int)(s.i[8 + k] & 0xffffffff); }
-      l.launch(fft_lines_mixed_kernel, s.grid, 256u, (unsigned)MIXED_LDS_BYTES, a);
+      {
+        const auto rcp = [](unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; };
+        unsigned nsp = 1;
+        for (int k = 0; k < a.nst; ++k) {
+          a.radix[k] = (int)(s.i[8 + k] >> 32); a.tw_off[k] = (int)(s.i[8 + k] & 0xffffffff);
+          a.rcp_nb[k] = rcp((unsigned)(a.N / a.radix[k])); a.rcp_nsp[k] = rcp(nsp);
+          nsp *= (unsigned)a.radix[k];
+        }
+      }
+      a.lds_bytes = (int)s.i[6];
+      l.launch(fft_lines_mixed_kernel, s.grid, (unsigned)s.i[7], (unsigned)(a.lds_bytes + MIXED_MAX_T * 8), a);
       return true;
     }
     case ST_STAGE: {

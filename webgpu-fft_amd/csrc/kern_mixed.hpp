@@ -3,6 +3,9 @@
 // stages (the global-memory stage route of kern_generic.hpp pays 16 B per point per stage).  The radix plan is a runtime
 // argument — one kernel serves every length — and each stage dispatches to a compile-time butterfly.
 // Replaces, for these lengths, the reference's one-dispatch-per-radix loop (`plan.js:1250-1259`, `stockham_stage.js:17-106`).
+// Measured (profiles/r01_mixed_radix.log): 54-106 GPoints/s, 3-16 % ahead of the stage route and insensitive to the LDS
+// budget / workgroup size — the runtime-plan stage loop is latency-bound, not bandwidth-bound; compile-time radix plans for
+// the common lengths (as the power-of-two line kernels have) are the next step.
 //
 // Lines of an N-D array as in StageArgs: line L -> (o = L / S, inner = L % S), element p at o*S*N + inner + p*S.
 // S == 1: lanes walk a line (LDS line-major);  S > 1: lanes walk T adjacent lines (LDS index-major) so that global
@@ -13,7 +16,8 @@
 
 namespace mi355 {
 
-constexpr int MIXED_LDS_BYTES = 64 * 1024;   // two buffers of T*N points
+constexpr int MIXED_MAX_T = 64;
+constexpr int MIXED_THREADS = 512;
 constexpr int MIXED_MAX_STAGES = 12;
 
 struct MixedArgs {
@@ -25,28 +29,34 @@ struct MixedArgs {
   int N, T, nst;
   int radix[MIXED_MAX_STAGES];
   int tw_off[MIXED_MAX_STAGES];       // elements
+  unsigned rcp_nb[MIXED_MAX_STAGES];  // ceil(2^32 / (N / R_s)): butterfly index -> line (0 when N/R_s == 1)
+  unsigned rcp_nsp[MIXED_MAX_STAGES]; // ceil(2^32 / Ns_prev)                          (0 when Ns_prev == 1)
   float scale;
   int swap_in, swap_out;
+  int lds_bytes;                      // bytes of the two line buffers; the per-line offsets sit behind them
 };
 
+// floor(n / d) for n < 2^20 through the precomputed reciprocal r = ceil(2^32 / d) (r == 0 encodes d == 1)
+MI_DEV unsigned mixed_div(unsigned n, unsigned r) { return r ? MI_UMULHI(n, r) : n; }
+
 template <int R>
-MI_DEV void mixed_stage(const MixedArgs& a, const cf* twp, int nsp, bool first, bool last, const cf* lin, cf* lout, long long L0, int tl) {
-  const int nb = a.N / R;
-  const int work = tl * nb;
+MI_DEV void mixed_stage(const MixedArgs& a, int s, int nsp, bool first, bool last, const cf* lin, cf* lout, const long long* s_base, int tl) {
+  const unsigned nb = (unsigned)(a.N / R);
+  const unsigned work = (unsigned)tl * nb;
   const bool row = a.S == 1;
-  for (int w = (int)threadIdx.x; w < work; w += (int)blockDim.x) {
-    int line, j;
-    if (row) { line = w / nb; j = w - line * nb; } else { j = w / tl; line = w - j * tl; }
-    const int k = j % nsp;
-    long long base = 0;
-    if (first || last) {
-      const long long L = L0 + line, o = L / a.S;
-      base = o * a.S * a.N + (L - o * a.S);
-    }
+  const cf* twp = a.tw + a.tw_off[s];
+  const unsigned rnb = a.rcp_nb[s], rnsp = a.rcp_nsp[s];
+  const unsigned rtl = tl > 1 ? (unsigned)((0x100000000ull + (unsigned)tl - 1) / (unsigned)tl) : 0u;
+  for (unsigned w = threadIdx.x; w < work; w += blockDim.x) {
+    unsigned line, j;
+    if (row) { line = mixed_div(w, rnb); j = w - line * nb; } else { j = mixed_div(w, rtl); line = w - j * (unsigned)tl; }
+    const unsigned blk = mixed_div(j, rnsp);          // j / Ns_prev
+    const unsigned k = j - blk * (unsigned)nsp;
+    const long long base = (first || last) ? s_base[line] : 0;
     cf v[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-      const int idx = j + q * nb;
+      const unsigned idx = j + q * nb;
       cf x;
       if (first) { x = a.in[base + (long long)idx * a.S]; if (a.swap_in) x = x.yx; }
       else x = lin[row ? line * a.N + idx : idx * a.T + line];
@@ -54,10 +64,10 @@ MI_DEV void mixed_stage(const MixedArgs& a, const cf* twp, int nsp, bool first, 
       v[q] = x;
     }
     fft_radix<R>(v);
-    const int ob = (j / nsp) * (nsp * R) + k;
+    const unsigned ob = blk * (unsigned)(nsp * R) + k;
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-      const int idx = ob + q * nsp;
+      const unsigned idx = ob + q * nsp;
       if (last) {
         cf y = v[q] * a.scale;
         if (a.swap_out) y = y.yx;
@@ -69,21 +79,26 @@ MI_DEV void mixed_stage(const MixedArgs& a, const cf* twp, int nsp, bool first, 
   }
 }
 
-static __global__ void __launch_bounds__(256) fft_lines_mixed_kernel(const MixedArgs a) {
+static __global__ void __launch_bounds__(MIXED_THREADS) fft_lines_mixed_kernel(const MixedArgs a) {
   MI_SMEM_DECL(smem);
   cf* buf[2] = {reinterpret_cast<cf*>(smem), reinterpret_cast<cf*>(smem) + (size_t)a.T * a.N};
+  long long* s_base = reinterpret_cast<long long*>(smem + a.lds_bytes);   // element offset of each line of the tile
   const long long tiles = (a.lines + a.T - 1) / a.T;
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long L0 = tile * a.T;
     const int tl = (int)((a.lines - L0) < (long long)a.T ? (a.lines - L0) : (long long)a.T);
+    if ((int)threadIdx.x < tl) {
+      const long long L = L0 + threadIdx.x, o = L / a.S;
+      s_base[threadIdx.x] = o * a.S * a.N + (L - o * a.S);
+    }
+    __syncthreads();
     int nsp = 1;
     for (int s = 0; s < a.nst; ++s) {
       const bool first = s == 0, last = s == a.nst - 1;
-      const cf* twp = a.tw + a.tw_off[s];
       const cf* lin = buf[(s + 1) & 1];
       cf* lout = buf[s & 1];
       switch (a.radix[s]) {
-#define MI_MIXED_CASE(R) case R: mixed_stage<R>(a, twp, nsp, first, last, lin, lout, L0, tl); break;
+#define MI_MIXED_CASE(R) case R: mixed_stage<R>(a, s, nsp, first, last, lin, lout, s_base, tl); break;
         MI_MIXED_CASE(2) MI_MIXED_CASE(3) MI_MIXED_CASE(4) MI_MIXED_CASE(5) MI_MIXED_CASE(7) MI_MIXED_CASE(8)
         MI_MIXED_CASE(11) MI_MIXED_CASE(13) MI_MIXED_CASE(16) MI_MIXED_CASE(32)
 #undef MI_MIXED_CASE

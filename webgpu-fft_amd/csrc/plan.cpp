@@ -112,6 +112,8 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
+  if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 8) o.xcd_split = v; }
@@ -378,14 +380,16 @@ struct Builder {
         for (int q = 0; q < R; ++q) for (int64_t k = 0; k < nsp; ++k) t[off + (size_t)(q * nsp + k)] = root_of_unity(q * k, nsp * R);
         nsp *= R;
       }
-      int64_t T = 4096 / N;                                            // two LDS buffers of T*N points in 64 KB
-      T = std::max<int64_t>(1, std::min<int64_t>(T, 64));
+      int64_t lds_kb = opt.mixed_lds_kb;
+      while (lds_kb * 64 < N) lds_kb *= 2;                              // two LDS buffers of T*N points (8 B each): T >= 1
+      const int64_t T = std::max<int64_t>(1, std::min<int64_t>(lds_kb * 64 / N, 64));
       st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
       st.i[0] = lines; st.i[1] = N; st.i[2] = S; st.i[3] = T; st.i[4] = ns;
-      st.i[5] = inverse ? 1 : 0;
+      st.i[5] = inverse ? 1 : 0; st.i[6] = lds_kb * 1024; st.i[7] = opt.mixed_threads;
       st.f[0] = scale;
       const int64_t tiles = (lines + T - 1) / T;
-      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)opt.compute_units * 2));
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(160 / (lds_kb + 1), 2048 / opt.mixed_threads));
+      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)opt.compute_units * per_cu));
       ir.route += "mixed-lines[N=" + std::to_string(N) + ",S=" + std::to_string(S) + ",T=" + std::to_string(T) + ",n=" + std::to_string(ns) + "] ";
       return MI355FFT_OK;
     }

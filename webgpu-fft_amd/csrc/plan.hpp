@@ -97,6 +97,8 @@ struct PlannerOptions {
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
+  int mixed_lds_kb = 64;               // LDS per workgroup of the mixed-radix line kernel (two buffers of T lines)
+  int mixed_threads = 256;
   int mixed_lines = 1;                 // mixed-radix lengths <= 4096: one LDS line kernel instead of one global pass per radix
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
 };

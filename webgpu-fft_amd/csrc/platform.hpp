@@ -61,3 +61,10 @@ void yield_thread();
 #define MI_SLEEP() emu::yield_thread()   /* bounded spins must outlast thread start-up of the other emulated blocks */
 #define MI_WAVE_SYNC() emu::sync_threads() /* emulated waves are not lock-step: use the block barrier */
 #endif
+
+// high 32 bits of a 32x32-bit product (v_mul_hi_u32): division by an invariant through a precomputed reciprocal
+#ifdef MI355_HOST_EMU
+#define MI_UMULHI(a, b) ((unsigned)(((unsigned long long)(a) * (unsigned long long)(b)) >> 32))
+#else
+#define MI_UMULHI(a, b) __umulhi((a), (b))
+#endif
