@@ -159,7 +159,7 @@ def main():
 
     if args.workload not in WORKLOADS:   # probes: c2c_2pL_bB / r2c_2pL_bB (never the headline line)
         import re
-        m = re.fullmatch(r"(c2c|r2c)_(2p|n)(\d+)_b(\d+)", args.workload)
+        m = re.fullmatch(r"(c2c|r2c|c2r)_(2p|n)(\d+)_b(\d+)", args.workload)
         if not m:
             raise SystemExit(f"unknown workload {args.workload}")
         nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
@@ -172,10 +172,14 @@ def main():
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n
         opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
-    else:
+    elif typ == "r2c":
         in_bytes, out_bytes = n * batch * 4, (n // 2 + 1) * batch * 8
         in_row_floats = n
         opts = {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+    else:   # c2r probe: random packed spectra (not Hermitian-consistent in bins 0 and N/2; irrelevant for timing)
+        in_bytes, out_bytes = (n // 2 + 1) * batch * 8, n * batch * 4
+        in_row_floats = 2 * (n // 2 + 1)
+        opts = {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "none"}
     need = in_bytes + out_bytes + (1 << 30)
     if info["hbm_free"] < need:
         raise SystemExit(f"workload {args.workload} needs {need >> 30} GiB of HBM, {info['hbm_free'] >> 30} GiB free")

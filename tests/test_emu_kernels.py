@@ -231,6 +231,44 @@ def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     check(got, want, f"xcd-r2c {label}", 1e-5)
 
 
+@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (6, 3, 1, 1), (8, 2, 2, 2), (9, 1, 8, 2)])
+def test_c2r_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
+    """Hermitian four-step c2r in one persistent launch (kern_xcd_real.hpp), test instance 64 x 64"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "2")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
+    n, batch = 4096, 7
+    p = n // 2 + 1
+    x = oracle.random_real_batch(n, batch, 0xD20D + cus).reshape(-1)
+    spec = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    for norm in ("backward", "none"):
+        desc = _abi.make_desc("c2r", [n], batch, "inverse", norm)
+        got, route, launches = emu.run_plan(desc, spec, n * batch)
+        assert route.startswith("xcd-c2r[N=64x64]") and launches == 2, route
+        want = np.concatenate([oracle.c2r_ref_from_packed(spec[2 * b * p:2 * (b + 1) * p], n, norm) for b in range(batch)])
+        check(got, want, f"xcd-c2r {norm} cus={cus}", 1e-5)
+        if norm == "backward":
+            check(got, x, "c2r(r2c(x)) = x", 1e-5)
+
+
+@pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024")])
+def test_c2r_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "4")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", "2")
+    n, batch = 1 << lg, 3
+    p = n // 2 + 1
+    x = oracle.random_real_batch(n, batch, 0xD300 + lg).reshape(-1)
+    spec = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward")
+    got, route, launches = emu.run_plan(desc, spec, n * batch)
+    assert route.startswith(f"xcd-c2r[N={label}]") and launches == 2, route
+    check(got, x, f"xcd-c2r {label}", 1e-5)
+
+
 def test_r2c_rejects_inverse_and_c2r_rejects_forward():
     for typ, direction, frag in (("r2c", "inverse", "forward"), ("c2r", "forward", "inverse")):
         desc = _abi.make_desc(typ, [16], 1, direction, "none")

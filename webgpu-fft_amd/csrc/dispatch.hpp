@@ -102,6 +102,16 @@ template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned
   }
   MI355_XCD_R2C_KERNEL_LIST(X)
 #undef X
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
+  if (id == cur++) {                                                                              \
+    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
+    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
+    using F = XcdFusedCfg<CA, CB>;                                                                \
+    l.launch_concurrent(fft_xcd_c2r_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
+    return true;                                                                                  \
+  }
+  MI355_XCD_C2R_KERNEL_LIST(X)
+#undef X
   (void)cur;
   return false;
 }

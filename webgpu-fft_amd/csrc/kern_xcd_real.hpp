@@ -154,4 +154,151 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// c2r: N/2+1 packed bins X of a real line -> the N real samples, one persistent launch, 16 B of traffic per real sample.
+// Replaces the reference's Hermitian unpack -> full complex inverse -> real part (`c2r.js:1743-1763`, `real_complex.js:116-201`)
+// and this library's half-length route (c2r_pre_kernel + inverse c2c) for dense power-of-two lines.
+//
+// x real  =>  x = IFFT(X) = FFT(conj X): a FORWARD four-step over the Hermitian sequence Xt = conj(X_full), input index
+// n = n1*N2 + n2 (bins), output index k1 + N1*k2 (samples).
+//   phase A  columns n2 = 0..N2/2 only (column N2-n2 is determined by column n2).  The upper half of a column (n1 < N1/2)
+//            is read conjugated from the stored bins; the lower half is the UNconjugated upper half of column N2-n2 walked
+//            backwards (Xt[n] = conj Xt[N-n]); column 0 mirrors onto itself one row lower.  Length-N1 complex FFT in LDS,
+//            stored as W[k1][n2], n2 <= N2/2.
+//   phase B  every row of W, times the four-step roots, is a Hermitian sequence in n2 whose transform is real: rows 2p and
+//            2p+1 are extended to full length (z[N2-n2] = conj z[n2]) and packed as z_a + i*z_b while they are loaded, one
+//            complex row FFT produces samples k1 = 2p (real part) and 2p+1 (imaginary part), which are ADJACENT in the
+//            output: the transposed store of the c2c pass B with N1/2 complex rows writes the real line directly.
+template <class CA, class CB>
+__global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFusedArgs f) {
+  static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
+  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL && CB::OUT_COL, "PASS_A then PASS_B");
+  static_assert(!CA::SWAP_IN && !CB::SWAP_OUT, "the conjugation is part of the loads");
+  static_assert(StageInfo<CA, 0>::NB == 1 && StageInfo<CB, 0>::NB == 1 && StageInfo<CA, 0>::R % 2 == 0 && StageInfo<CB, 0>::R % 2 == 0,
+                "first radix = values per thread, even");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
+  using TB = XcdTables<CA, CB>;
+  cf* tw_a = lds + DATA;
+  cf* tw_b = TB::SHARED ? tw_a : tw_a + CA::TW_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw_a + TB::ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
+  if constexpr (!TB::SHARED) { for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i]; }
+
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+
+  constexpr int N1 = CA::N, N2 = CB::N, COLS = N2 / 2 + 1, WP = N2 / 2 + 16;   // live columns, row pitch of W
+  const long long wsize = (long long)N1 * WP;
+  LineArgs aa{}, ab{};
+  aa.tw = f.tw_a; aa.num_tiles = (COLS + CA::T - 1) / CA::T; aa.num_lines = COLS;
+  aa.out_S = WP; aa.out_outer_stride = wsize; aa.scale = 1.0f; aa.fs_group = 1;
+  ab.tw = f.tw_b; ab.num_tiles = (N1 / 2) / CB::T; ab.num_lines = N1 / 2;
+  ab.out_S = N1 / 2; ab.out_outer_stride = f.N / 2; ab.scale = f.scale; ab.fs_group = N1;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)wsize;
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)wsize;
+    // ---- phase A ----
+    const cf* const X = f.in + tr * f.in_pitch;
+    aa.out = W;
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CA>(i, rank, gsize);
+      if (tile - (i % PairOf<CA>::C) >= aa.num_tiles) break;
+      if (tile >= aa.num_tiles) continue;
+      cf v[CA::E];
+      {
+        using I = StageInfo<CA, 0>;
+        int line, u; thread_map<CA, 0>(t, line, u);
+        int n2 = (int)(tile * CA::T) + line;
+        if (n2 > N2 / 2) n2 = N2 / 2;                       // padding lines of the last tile re-read its live column
+        const int up = u * N2 + n2;                          // n1 = u + q*(N1/R): upper half, conjugated
+        const int lo = n2 ? (N1 - 1 - u) * N2 + (N2 - n2) : (N1 - u) * N2;   // lower half: mirrored element, as stored
+#pragma unroll
+        for (int q = 0; q < I::R; ++q) {
+          const int step = q * (N1 / I::R) * N2;             // uniform
+          if (q < I::R / 2) { const cf x = ld_stream<PairOf<CA, false>::NT>(X + (up + step)); v[q] = cf{x.x, -x.y}; }
+          else v[q] = ld_stream<PairOf<CA, false>::NT>(X + (lo - step));
+        }
+      }
+      stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
+      __syncthreads();
+      stage_read<CA, 1>(v, aa, tile, t, lds);
+      __syncthreads();
+      stage_compute_write<CA, 1>(v, aa, tile, t, lds, tw_a, nullptr);
+      if constexpr (CA::NSTAGES == 3) {
+        __syncthreads();
+        stage_read<CA, 2>(v, aa, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CA, 2>(v, aa, tile, t, lds, tw_a, nullptr);
+      }
+      __syncthreads();
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B ----
+    ab.out = f.out + tr * f.out_pitch;
+    for (long long i = 0;; ++i) {
+      const long long tile = xcd_tile<CB>(i, rank, gsize);
+      if (tile - (i % PairOf<CB>::C) >= ab.num_tiles) break;
+      if (tile >= ab.num_tiles) continue;
+      cf v[CB::E];
+      {
+        using I = StageInfo<CB, 0>;
+        constexpr int H = I::R / 2, STR = N2 / I::R;
+        int line, u; thread_map<CB, 0>(t, line, u);
+        const unsigned ka = 2u * (unsigned)(tile * CB::T + line), kb = ka + 1u;
+        const cf* const wa = W + (size_t)ka * WP;
+        const cf* const wb = wa + WP;
+        const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
+        const cf step_a = root(ka * (unsigned)STR), step_b = root(kb * (unsigned)STR);
+        // first half of the thread's elements: n2 = u + q*STR < N2/2, read as stored.  Roots e^{-2 pi i k1 n2/N}: exact
+        // lookups every 8th element, the recurrence with the per-row step between
+#pragma unroll
+        for (int g = 0; g < H; g += 8) {
+          cf ra = root(ka * (unsigned)(u + g * STR)), rb = root(kb * (unsigned)(u + g * STR));
+#pragma unroll
+          for (int q = g; q < g + 8 && q < H; ++q) {
+            const cf a = cmul(wa[u + q * STR], ra), b = cmul(wb[u + q * STR], rb);
+            v[q] = cf{a.x - b.y, a.y + b.x};
+            ra = cmul(ra, step_a); rb = cmul(rb, step_b);
+          }
+        }
+        // second half: n2 = u + (H + q')*STR > N2/2 (= N2/2 for u = 0, q' = 0) is the conjugate of column
+        // m = N2 - n2 = (STR - u) + q*STR with q = H - 1 - q'
+#pragma unroll
+        for (int g = 0; g < H; g += 8) {
+          cf ra = root(ka * (unsigned)((STR - u) + g * STR)), rb = root(kb * (unsigned)((STR - u) + g * STR));
+#pragma unroll
+          for (int q = g; q < g + 8 && q < H; ++q) {
+            const int m = (STR - u) + q * STR;
+            const cf a = cmul(wa[m], ra), b = cmul(wb[m], rb);
+            v[I::R - 1 - q] = cf{a.x + b.y, b.x - a.y};     // conj(a) + i*conj(b)
+            ra = cmul(ra, step_a); rb = cmul(rb, step_b);
+          }
+        }
+      }
+      stage_compute_write<CB, 0, PairOf<CB, false>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
+      __syncthreads();
+      stage_read<CB, 1>(v, ab, tile, t, lds);
+      __syncthreads();
+      stage_compute_write<CB, 1, PairOf<CB, false>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
+      if constexpr (CB::NSTAGES == 3) {
+        __syncthreads();
+        stage_read<CB, 2>(v, ab, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CB, 2, PairOf<CB, false>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
+      }
+      __syncthreads();
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
+
 }  // namespace mi355

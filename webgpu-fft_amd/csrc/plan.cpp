@@ -94,12 +94,15 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     r.push_back(m);                                                                                       \
   }
 #define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
-  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, false)                                          \
-  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, true, false)
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, 0)                                          \
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, true, 0)
     MI355_XCD_KERNEL_LIST(X)
 #undef X
-#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, true)
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, 1)
     MI355_XCD_R2C_KERNEL_LIST(X)
+#undef X
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, 2)
+    MI355_XCD_C2R_KERNEL_LIST(X)
 #undef X
 #undef XCD_META
     return r;
@@ -224,16 +227,16 @@ struct Builder {
   }
 
   // XCD-fused r2c of `lines` dense real lines of length N into packed spectra of N/2+1 bins; false if no instance applies
-  bool emit_xcd_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale) {
+  bool emit_xcd_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false) {
     if (opt.force_generic || !opt.xcd_fused || !opt.xcd_r2c || opt.only_pass || N < 4096 || (N & (N - 1))) return false;
     const int lgf = lg2(N);
     const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
     const XcdKernelMeta* xm = nullptr;
-    for (const auto& m : xcd_kernel_registry()) if (m.real && m.N1 == F1 && m.N2 == F2) xm = &m;
+    for (const auto& m : xcd_kernel_registry()) if (m.real == (c2r ? 2 : 1) && m.N1 == F1 && m.N2 == F2) xm = &m;
     if (!xm || (N <= 8192 && opt.xcd_fused != 2)) return false;
     const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
-    const int64_t wsize = (F1 / 2 + 1) * F2;                       // rows 0..N1/2 of the intermediate
+    const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
     const int64_t split = xcd_split_for((uint64_t)wsize * 8);
     const PtrRef wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * wsize * 8);
     const PtrRef ctl = alloc_work(16384);
@@ -246,11 +249,12 @@ struct Builder {
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
     st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
-    st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N / 2; st.i[10] = N / 2 + 1;
+    st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1;
+    st.i[9] = c2r ? N / 2 + 1 : N / 2; st.i[10] = c2r ? N / 2 : N / 2 + 1;        // pitches in complex elements
     st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = opt.xcd_slots;
     st.f[0] = scale;
     st.grid = (unsigned)opt.compute_units;
-    ir.route += "xcd-r2c[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    ir.route += std::string(c2r ? "xcd-c2r[N=" : "xcd-r2c[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
     return true;
   }
 
@@ -810,7 +814,9 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     int rc = b.emit_nd(packed, packed, ps, d.rank, d.batch, true, 1.0f, err, 1);
     if (rc) return rc;
   }
-  if (N % 2 == 0) {
+  if (b.emit_xcd_r2c(packed, out, N, lines, scale, true)) {
+    // one persistent launch: Hermitian four-step (kern_xcd_real.hpp)
+  } else if (N % 2 == 0) {
     const int64_t H = N / 2;
     PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
     Step& st = b.push(ST_C2R_PRE);
