@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
             v[q] = cf{a.x - b.y, a.y + b.x};
             ra = cmul(ra, step_a); rb = cmul(rb, step_b);
           }
+          MI_SCHED_FENCE();
         }
         // second half: n2 = u + (H + q')*STR > N2/2 (= N2/2 for u = 0, q' = 0) is the conjugate of column
         // m = N2 - n2 = (STR - u) + q*STR with q = H - 1 - q'
@@ -279,6 +280,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
             v[I::R - 1 - q] = cf{a.x + b.y, b.x - a.y};     // conj(a) + i*conj(b)
             ra = cmul(ra, step_a); rb = cmul(rb, step_b);
           }
+          MI_SCHED_FENCE();
         }
       }
       stage_compute_write<CB, 0, PairOf<CB, false>::NT>(v, ab, tile, t, lds, tw_b, nullptr);

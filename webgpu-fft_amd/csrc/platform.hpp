@@ -68,3 +68,11 @@ void yield_thread();
 #else
 #define MI_UMULHI(a, b) __umulhi((a), (b))
 #endif
+
+// keeps the instruction scheduler from moving anything across this point (caps the loads in flight, and with them the
+// registers they pin, in long unrolled load/compute sequences)
+#ifdef MI355_HOST_EMU
+#define MI_SCHED_FENCE() do { } while (0)
+#else
+#define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
