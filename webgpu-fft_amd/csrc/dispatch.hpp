@@ -8,6 +8,7 @@
 //   template <class... P, class... A> void launch(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args);
 //   void copy(void* dst, const void* src, size_t bytes);
 #pragma once
+#include <utility>
 #include "kern_fftconv.hpp"
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
@@ -72,48 +73,64 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
   return false;
 }
 
-// XCD-fused four-step kernels live in their own translation unit in the product build (lines_fam_xcd.hip)
-template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
-  int cur = 0;
-#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
-  if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
-    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
-    using F = XcdFusedCfg<CA, CB>;                                                                \
-    l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
-    return true;                                                                                  \
-  }                                                                                               \
-  if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, true, false, 0>;                           \
-    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, true, 0>;                          \
-    using F = XcdFusedCfg<CA, CB>;                                                                \
-    l.launch_concurrent(fft_xcd_fused_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
-    return true;                                                                                  \
+// XCD-fused kernels.  Instance ids follow the registry order of plan.cpp (c2c forward/inverse per entry, then r2c, then c2r).
+// In the product build EVERY instance is compiled in its own translation unit (lines_xcd_one.hip with -DMI355_XCD_ID=k):
+// these kernels sit at the edge of the 256-VGPR budget and the register allocation of one and the same kernel changed with
+// the other kernels of its translation unit (e.g. 1024x2048 c2c: 247 VGPRs and no scratch alone, 256 VGPRs and 92 B of scratch
+// per lane in a unit with eleven siblings; r2c 1024x2048: 88 B against 264 B).
+#define MI_XCD_PLUS2(...) +2
+#define MI_XCD_PLUS1(...) +1
+constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1);
+#undef MI_XCD_PLUS2
+#undef MI_XCD_PLUS1
+
+// ONLY < 0: every instance (host emulation); ONLY = k: instance k alone is instantiated, the others fall through
+template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, unsigned grid, L& l);
+
+#if defined(MI355_XCD_DEFINE_INSTANCES) || defined(MI355_HOST_EMU)
+enum { MI_XCD_COUNTER_BASE = __COUNTER__ + 1 };
+#define MI_XCD_CASE(KERNEL, SWAP)                                                                  \
+  {                                                                                               \
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;                                         \
+    if constexpr (ONLY < 0 || ONLY == ME) {                                                       \
+      if (id == ME) {                                                                             \
+        using CA = LineCfg<N1_, A0_, A1_, A2_, TA_, true, true, SWAP, false, 0>;                   \
+        using CB = LineCfg<N2_, B0_, B1_, B2_, TB_, false, true, false, SWAP, 0>;                  \
+        using F = XcdFusedCfg<CA, CB>;                                                            \
+        l.launch_concurrent(KERNEL<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
+        return true;                                                                              \
+      }                                                                                           \
+    }                                                                                             \
   }
+#define MI_XCD_PARAMS(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) \
+  constexpr int N1_ = N1, A0_ = A0, A1_ = A1, A2_ = A2, TA_ = TA, N2_ = N2, B0_ = B0, B1_ = B1, B2_ = B2, TB_ = TB;
+template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
+#define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_fused_kernel, false) MI_XCD_CASE(fft_xcd_fused_kernel, true) }
   MI355_XCD_KERNEL_LIST(X)
 #undef X
-#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
-  if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
-    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
-    using F = XcdFusedCfg<CA, CB>;                                                                \
-    l.launch_concurrent(fft_xcd_r2c_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
-    return true;                                                                                  \
-  }
+#define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_r2c_kernel, false) }
   MI355_XCD_R2C_KERNEL_LIST(X)
 #undef X
-#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                  \
-  if (id == cur++) {                                                                              \
-    using CA = LineCfg<N1, A0, A1, A2, TA, true, true, false, false, 0>;                          \
-    using CB = LineCfg<N2, B0, B1, B2, TB, false, true, false, false, 0>;                         \
-    using F = XcdFusedCfg<CA, CB>;                                                                \
-    l.launch_concurrent(fft_xcd_c2r_kernel<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
-    return true;                                                                                  \
-  }
+#define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_c2r_kernel, false) }
   MI355_XCD_C2R_KERNEL_LIST(X)
 #undef X
-  (void)cur;
+  static_assert(__COUNTER__ - MI_XCD_COUNTER_BASE == XCD_INSTANCE_COUNT, "instance ids out of step with the lists");
   return false;
+}
+#undef MI_XCD_CASE
+#undef MI_XCD_PARAMS
+#endif
+
+template <class L, int... Is>
+bool launch_xcd_fold(int id, const XcdFusedArgs& a, unsigned grid, L& l, std::integer_sequence<int, Is...>) {
+  return ((id == Is && launch_xcd_sel<Is, L>(id, a, grid, l)) || ...);
+}
+template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
+#ifdef MI355_HOST_EMU
+  return launch_xcd_sel<-1, L>(id, a, grid, l);
+#else
+  return launch_xcd_fold(id, a, grid, l, std::make_integer_sequence<int, XCD_INSTANCE_COUNT>{});
+#endif
 }
 
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {

@@ -55,6 +55,5 @@ extern template bool launch_lines_family<FAM_ROW_1K, HipLauncher>(int, const Lin
 extern template bool launch_lines_family<FAM_ROW_BIG, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 extern template bool launch_lines_family<FAM_PASS_A, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 extern template bool launch_lines_family<FAM_PASS_B, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
-extern template bool launch_xcd_fused<HipLauncher>(int, const XcdFusedArgs&, unsigned, HipLauncher&);
 
 }  // namespace mi355
