@@ -123,7 +123,7 @@ def test_c2c_in_place_and_offsets(fft, dev, oracle):
     out.destroy()
 
 
-FUSED_LG = (18, 19, 20, 21)   # MI355_XCD_KERNEL_LIST (plan.hpp)
+FUSED_LG = (18, 19, 20, 21)   # 2^22 stays on the two-launch route   # MI355_XCD_KERNEL_LIST (plan.hpp)
 
 
 @pytest.mark.parametrize("fused", [0, 1])
