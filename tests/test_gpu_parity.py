@@ -172,7 +172,7 @@ def test_c2c_large_golden_samples(fft, dev, oracle, manifest):
 @pytest.mark.parametrize("n", [3, 5, 6, 7, 11, 12, 13, 15, 21, 96, 105, 210, 1000, 1001, 1144, 2187, 3000, 4095, 3 * 4096])
 def test_c2c_mixed_radix(fft, dev, oracle, monkeypatch, n, mixed):
     """mixed-radix lengths: the one-launch LDS line kernel (N <= 4096, >= 2 stages) and the global-memory stage route"""
-    monkeypatch.setenv("MI355FFT_MIXED_LINES", str(mixed))
+    monkeypatch.setenv("MI355FFT_MIXED_LINES", str(2 * mixed))   # 2: also where the planner would keep the stage route
     batch = 300 if n < 200 else (37 if n < 2000 else 5)   # several tiles per workgroup, ragged last tile; the O(N^2) oracle bounds the rest
     x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):

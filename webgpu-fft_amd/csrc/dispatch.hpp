@@ -186,8 +186,8 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
           nsp *= (unsigned)a.radix[k];
         }
       }
-      a.lds_bytes = (int)s.i[6];
-      l.launch(fft_lines_mixed_kernel, s.grid, (unsigned)s.i[7], (unsigned)(a.lds_bytes + MIXED_MAX_T * 8), a);
+      a.lds_bytes = (int)s.i[6]; a.tw_total = (int)s.i[19];
+      l.launch(fft_lines_mixed_kernel, s.grid, (unsigned)s.i[7], (unsigned)(a.lds_bytes + MIXED_MAX_T * 8 + a.tw_total * 8), a);
       return true;
     }
     case ST_STAGE: {

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
-#include <unordered_set>
+#include <unordered_map>
 
 #include "dispatch.hpp"
 
@@ -25,12 +25,13 @@ struct HipLauncher {
 
   static void raise_lds_limit(const void* fn, unsigned smem, hipError_t& status) {
     static std::mutex mu;
-    static std::unordered_set<const void*> done;
+    static std::unordered_map<const void*, unsigned> raised;   // kernels with a runtime LDS size (kern_mixed.hpp) may ask for more later
     std::lock_guard<std::mutex> g(mu);
-    if (done.count(fn)) return;
+    const auto it = raised.find(fn);
+    if (it != raised.end() && it->second >= smem) return;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { status = e; return; }
-    done.insert(fn);
+    raised[fn] = smem;
   }
 
   template <class... P, class... A>

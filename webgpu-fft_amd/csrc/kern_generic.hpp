@@ -75,6 +75,17 @@ static __global__ void __launch_bounds__(256) scale_kernel(float* data, long lon
 //   X[k] = (Z[k] + conj(Z[H-k]))/2 - (i/2) e^{-2 pi i k/N} (Z[k] - conj(Z[H-k])),  Z[H] := Z[0]
 // The root e^{-2 pi i k/N} is formed as HI[k >> shift] * LO[k & mask] from two small cache-resident tables, not
 // read from an (N/2+1)-entry table: at N = 2^22 that table would add 4 B per complex point of fabric traffic.
+// the split passes stream every byte exactly once: nontemporal accesses (MI355_POST_NT, measured in profiles/r01_xcd_fused_ab.log)
+#ifndef MI355_POST_NT
+#define MI355_POST_NT 0
+#endif
+#if MI355_POST_NT
+#define MI_POST_LD(p) __builtin_nontemporal_load(p)
+#define MI_POST_ST(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MI_POST_LD(p) (*(p))
+#define MI_POST_ST(p, v) (*(p) = (v))
+#endif
 struct R2cPostArgs {
   const cf* z; cf* x; const cf* tw_lo; const cf* tw_hi;
   long long H, batch;
@@ -100,8 +111,8 @@ static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs 
     for (int j = 0; j < U; ++j) {
       const long long k = k0 + j * 256;
       const long long kc = k < per ? k : 0;            // clamp: out-of-range lanes read bin 0 and store nothing
-      zk[j] = z[kc];
-      zm[j] = z[kc == 0 ? 0 : a.H - kc];
+      zk[j] = MI_POST_LD(z + kc);
+      zm[j] = MI_POST_LD(z + (kc == 0 ? 0 : a.H - kc));
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -116,9 +127,9 @@ static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs 
       const cf xk = (e + wo) * a.scale;
       cf xm = (e - wo) * a.scale;
       xm.y = -xm.y;
-      x[k] = xk;
-      if (k == 0) x[a.H] = xm;            // X[H] = E[0] - O[0]
-      else if (km != k) x[km] = xm;
+      MI_POST_ST(x + k, xk);
+      if (k == 0) MI_POST_ST(x + a.H, xm);            // X[H] = E[0] - O[0]
+      else if (km != k) MI_POST_ST(x + km, xm);
     }
   }
 }

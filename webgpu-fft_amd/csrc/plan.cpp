@@ -125,15 +125,18 @@ PlannerOptions planner_options_from_env() {
   return o;
 }
 
-std::vector<int> factorize_radices(int64_t n) {
+// max_radix < 32: the one-launch mixed-radix kernel keeps a line in LDS, where a stage is cheap but its parallelism is
+// N / radix butterflies per line — radices above 8 starve the workgroup (measured: N = 640 as 32*4*5 30 GPoints/s)
+std::vector<int> factorize_radices(int64_t n, int max_radix) {
   static const int allowed[] = {32, 16, 8, 4, 2, 13, 11, 7, 5, 3};
   std::vector<int> out;
-  for (int r : allowed)
+  for (int r : allowed) {
+    if (r > max_radix && (r & (r - 1)) == 0) continue;
     while (n % r == 0 && n > 1) { out.push_back(r); n /= r; }
+  }
   if (n != 1) out.clear();
   return out;
 }
-
 float2h root_of_unity(int64_t m, int64_t M) {
   m %= M;
   if (m < 0) m += M;
@@ -370,8 +373,13 @@ struct Builder {
     // generic: one global-memory Stockham stage per radix
     const std::vector<int> radices = factorize_radices(N);
     if (radices.empty()) return emit_bluestein(src, dst, N, S, outer, inverse, scale, err);
-    const int ns = (int)radices.size();
-    if (opt.mixed_lines && !opt.force_generic && ns >= 2 && ns <= 12 && N <= 4096) {
+    int ns = (int)radices.size();
+    const std::vector<int> lds_radices = factorize_radices(N, 8);
+    // (short lines that the stage route finishes in three passes with a radix-16/32 first stage measured faster there: 640, 768)
+    const bool stages_win = S == 1 && N < 1024 && radices.size() == 3 && radices[0] >= 16 && opt.mixed_lines != 2;
+    if (opt.mixed_lines && !opt.force_generic && !stages_win && lds_radices.size() >= 2 && lds_radices.size() <= 12 && N <= 4096) {
+      const std::vector<int>& radices = lds_radices;
+      ns = (int)radices.size();
       // all stages in one launch, T lines per workgroup in LDS (kern_mixed.hpp)
       std::vector<float2h> t;
       Step& st = push(ST_LINES_MIXED);
@@ -384,15 +392,21 @@ struct Builder {
         for (int q = 0; q < R; ++q) for (int64_t k = 0; k < nsp; ++k) t[off + (size_t)(q * nsp + k)] = root_of_unity(q * k, nsp * R);
         nsp *= R;
       }
-      int64_t lds_kb = opt.mixed_lds_kb;
-      while (lds_kb * 64 < N) lds_kb *= 2;                              // two LDS buffers of T*N points (8 B each): T >= 1
-      const int64_t T = std::max<int64_t>(1, std::min<int64_t>(lds_kb * 64 / N, 64));
+      // Tile and workgroup shape from the sweeps in profiles/r01_mixed_radix.log: short lines fill a 64 KB pair of buffers
+      // (T lines, 256 threads); from N = 512 on one line per workgroup, threads ~ N/8, and as many workgroups per CU as fit.
+      // The stage tables ride in LDS when they are small (<= 16 KB); longer ones are read through the caches.
+      int64_t T, threads;
+      if (opt.mixed_lds_kb > 0) { T = std::max<int64_t>(1, std::min<int64_t>(opt.mixed_lds_kb * 64 / N, 64)); threads = opt.mixed_threads; }
+      else if (N < 512 || S > 1) { T = std::max<int64_t>(1, std::min<int64_t>(4096 / N, 64)); threads = 256; }   // strided axes: lanes walk T lines
+      else { T = 1; threads = std::max<int64_t>(64, std::min<int64_t>(256, ((N / 8 + 63) / 64) * 64)); }
+      const int64_t lds_bytes = 2 * T * (N + (N >> 5) + 1) * 8;          // kern_mixed.hpp mixed_pitch
+      const int64_t tw_lds = (int64_t)t.size() * 8 <= 16 * 1024 ? (int64_t)t.size() : 0;
       st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
       st.i[0] = lines; st.i[1] = N; st.i[2] = S; st.i[3] = T; st.i[4] = ns;
-      st.i[5] = inverse ? 1 : 0; st.i[6] = lds_kb * 1024; st.i[7] = opt.mixed_threads;
+      st.i[5] = inverse ? 1 : 0; st.i[6] = lds_bytes; st.i[7] = threads; st.i[19] = tw_lds;
       st.f[0] = scale;
       const int64_t tiles = (lines + T - 1) / T;
-      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(160 / (lds_kb + 1), 2048 / opt.mixed_threads));
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / (lds_bytes + tw_lds * 8 + 1024), 2048 / threads), 8));
       st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)opt.compute_units * per_cu));
       ir.route += "mixed-lines[N=" + std::to_string(N) + ",S=" + std::to_string(S) + ",T=" + std::to_string(T) + ",n=" + std::to_string(ns) + "] ";
       return MI355FFT_OK;

@@ -102,7 +102,7 @@ struct PlannerOptions {
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
-  int mixed_lds_kb = 64;               // LDS per workgroup of the mixed-radix line kernel (two buffers of T lines)
+  int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
   int mixed_lines = 1;                 // mixed-radix lengths <= 4096: one LDS line kernel instead of one global pass per radix
   int only_pass = 0;                   // measurement aid (bench.py per-kernel timing): 1 = emit pass A only, 2 = pass B only
@@ -114,7 +114,7 @@ int build_plan(const mi355fft_plan_desc& desc, const PlannerOptions& opt, PlanIR
 
 // radix factorisation of the generic route: greedy largest-first over {32,16,8,4,2,13,11,7,5,3}
 // (superset of src/plan.js:20-33's {13,11,8,7,5,4,3,2}); empty when n has another prime factor
-std::vector<int> factorize_radices(int64_t n);
+std::vector<int> factorize_radices(int64_t n, int max_radix = 32);
 
 // e^{-2 pi i m / M} rounded to f32 from an 80-bit evaluation
 float2h root_of_unity(int64_t m, int64_t M);
