@@ -4,7 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
-#include <unordered_map>
+#include <map>
+#include <utility>
 
 #include "dispatch.hpp"
 
@@ -25,13 +26,18 @@ struct HipLauncher {
 
   static void raise_lds_limit(const void* fn, unsigned smem, hipError_t& status) {
     static std::mutex mu;
-    static std::unordered_map<const void*, unsigned> raised;   // kernels with a runtime LDS size (kern_mixed.hpp) may ask for more later
+    // per (device, kernel): the attribute belongs to the device's copy of the code object; kernels with a runtime LDS size
+    // (kern_mixed.hpp) may ask for more later
+    static std::map<std::pair<int, const void*>, unsigned> raised;
     std::lock_guard<std::mutex> g(mu);
-    const auto it = raised.find(fn);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const auto key = std::make_pair(dev, fn);
+    const auto it = raised.find(key);
     if (it != raised.end() && it->second >= smem) return;
     const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) { status = e; return; }
-    raised[fn] = smem;
+    raised[key] = smem;
   }
 
   template <class... P, class... A>
