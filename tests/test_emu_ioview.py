@@ -110,4 +110,145 @@ def test_view_validation_messages():
             resolve_plan_options(dict({"type": "c2c", "shape": [8, 4], "direction": "forward"}, **extra))
         assert frag in str(e.value)
     with pytest.raises(NotImplementedError):
-        resolve_plan_options({"type": "r2c", "shape": [8], "direction": "forward", "zeroPad": {"read": {"start": [1], "end": [8]}}})
+        resolve_plan_options({"type": "fftconv", "shape": [8], "fftConv": {"kernelCount": 1}, "zeroPad": {"read": {"start": [1], "end": [8]}}})
+    with pytest.raises(ValueError) as e:    # r2c writes the packed domain: shape[0] // 2 + 1 = 5 bins
+        resolve_plan_options({"type": "r2c", "shape": [8], "direction": "forward", "zeroPad": {"write": {"start": [0], "end": [6]}}})
+    assert "zeroPad.write.end[0] must be <= shape[0] (5); got 6" in str(e.value)
+
+
+# ---- r2c / c2r: the views of the real side live on the real domain, those of the spectrum side on the packed one ----
+def _embed(x, lshape, view, batch, width):
+    """physical view array -> zero-filled logical domain (width = 1 real / 2 complex floats per element)"""
+    rank = len(lshape)
+    logical = np.zeros((batch, *reversed(lshape), width), np.float32)
+    if not view:
+        return x.reshape(logical.shape).copy()
+    v = x.reshape(batch, *reversed(view["shape"]), width)
+    for idx in np.ndindex(*reversed(lshape)):
+        c = idx[::-1]
+        vc = [c[d] - view["offset"][d] for d in range(rank)]
+        if all(0 <= vc[d] < view["shape"][d] for d in range(rank)):
+            logical[(slice(None), *idx)] = v[(slice(None), *vc[::-1])]
+    return logical
+
+
+def _extract(y, lshape, view, batch, width, out_init):
+    rank = len(lshape)
+    if not view:
+        return y.reshape(-1)
+    out = np.asarray(out_init, np.float32).reshape(batch, *reversed(view["shape"]), width).copy()
+    if view.get("clearOutside"):
+        out[...] = 0
+    for idx in np.ndindex(*reversed(view["shape"])):
+        vc = idx[::-1]
+        lc = [vc[d] + view["offset"][d] for d in range(rank)]
+        if all(0 <= lc[d] < lshape[d] for d in range(rank)):
+            out[(slice(None), *idx)] = y[(slice(None), *lc[::-1])]
+    return out.reshape(-1)
+
+
+def _zero_outside(a, lshape, z):
+    if z:
+        keep = np.zeros(tuple(reversed(lshape)), bool)
+        keep[_box(lshape, z["start"], z["end"])] = True
+        a[:, ~keep] = 0
+
+
+REAL_CASES = [
+    ([16], {"input": {"shape": [10]}}, None),
+    ([16], {"input": {"shape": [20], "offset": [-2]}, "output": {"shape": [5], "offset": [2]}}, None),
+    ([16], {"output": {"shape": [12], "placement": "center", "clearOutside": True}}, {"read": {"start": [3], "end": [13]}}),
+    ([16, 4], {"input": {"shape": [12, 3], "offset": [1, 1]}}, {"write": {"start": [1, 0], "end": [8, 3]}}),
+    ([64], None, {"read": {"start": [8], "end": [56]}, "write": {"start": [0], "end": [20]}}),
+]
+
+
+@pytest.mark.parametrize("shape,io_view,zero_pad", REAL_CASES)
+def test_r2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
+    batch = 2
+    opts = {"type": "r2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "none"}
+    if io_view:
+        opts["ioView"] = io_view
+    if zero_pad:
+        opts["zeroPad"] = zero_pad
+    desc, r = _desc(opts)
+    packed = [shape[0] // 2 + 1] + shape[1:]
+    vin, vout = r["io_view"]["input"], r["io_view"]["output"]
+    in_shape = vin["shape"] if vin else shape
+    out_shape = vout["shape"] if vout else packed
+    x = oracle.random_real_batch(int(np.prod(in_shape)), batch, 4242 + sum(shape)).reshape(-1)
+    out_floats = 2 * int(np.prod(out_shape)) * batch
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
+    got, route, _ = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    logical = _embed(x, shape, vin, batch, 1)
+    _zero_outside(logical, shape, r["zero_pad"]["read"])
+    cplx = np.zeros((batch, *reversed(shape), 2), np.float32)
+    cplx[..., 0] = logical[..., 0]
+    full = oracle.c2c_ref_batch(cplx.reshape(-1), shape, batch, "forward", "none").reshape(batch, *reversed(shape), 2)
+    y = full[..., :packed[0], :].copy()
+    _zero_outside(y, packed, r["zero_pad"]["write"])
+    want = _extract(y, packed, vout, batch, 2, sentinel)
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert got.shape == want.shape and float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, route
+
+
+@pytest.mark.parametrize("shape,io_view,zero_pad", [
+    ([16], {"output": {"shape": [10], "offset": [3]}}, None),
+    ([16], {"input": {"shape": [6]}}, {"write": {"start": [2], "end": [14]}}),                  # low-pass: only the first 6 bins given
+    ([16, 4], {"output": {"shape": [20, 4], "placement": "center", "clearOutside": True}}, {"read": {"start": [0, 0], "end": [5, 4]}}),
+])
+def test_c2r_ioview_zeropad(oracle, shape, io_view, zero_pad):
+    batch = 2
+    opts = {"type": "c2r", "shape": shape, "batch": batch, "direction": "inverse", "normalize": "backward"}
+    if io_view:
+        opts["ioView"] = io_view
+    if zero_pad:
+        opts["zeroPad"] = zero_pad
+    desc, r = _desc(opts)
+    packed = [shape[0] // 2 + 1] + shape[1:]
+    vin, vout = r["io_view"]["input"], r["io_view"]["output"]
+    in_shape = vin["shape"] if vin else packed
+    out_shape = vout["shape"] if vout else shape
+    # a Hermitian-consistent spectrum: r2c of a random real signal, cropped to the physical input view
+    n = int(np.prod(shape))
+    sig = oracle.random_real_batch(n, batch, 777 + sum(shape)).reshape(batch, *reversed(shape))
+    cplx = np.zeros((batch, *reversed(shape), 2), np.float32)
+    cplx[..., 0] = sig
+    spec = oracle.c2c_ref_batch(cplx.reshape(-1), shape, batch, "forward", "none").reshape(batch, *reversed(shape), 2)[..., :packed[0], :].copy()
+    if vin:      # physical input = the view's window of the packed spectrum (zeros where the window leaves it)
+        phys = np.zeros((batch, *reversed(in_shape), 2), np.float32)
+        for idx in np.ndindex(*reversed(in_shape)):
+            lc = [idx[::-1][d] + vin["offset"][d] for d in range(len(shape))]
+            if all(0 <= lc[d] < packed[d] for d in range(len(shape))):
+                phys[(slice(None), *idx)] = spec[(slice(None), *lc[::-1])]
+        x = phys.reshape(-1)
+    else:
+        x = spec.reshape(-1)
+    out_floats = int(np.prod(out_shape)) * batch
+    sentinel = np.full(out_floats, 77.0, np.float32)
+    got, route, _ = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    logical = _embed(x, packed, vin, batch, 2)
+    _zero_outside(logical, packed, r["zero_pad"]["read"])
+    p = packed[0]
+    lines = logical.reshape(-1, p, 2)
+    if len(shape) == 1:
+        y = np.stack([oracle.c2r_ref_from_packed(l.reshape(-1), shape[0], "backward") for l in lines]).reshape(batch, shape[0], 1)
+    else:
+        # N-D: inverse c2c over the other axes of the Hermitian-extended array, via the full complex oracle
+        full = np.zeros((batch, *reversed(shape), 2), np.float32)
+        full[..., :p, :] = logical
+        for k in range(1, shape[0] - p + 1):
+            src = logical[..., p - 1 - k if shape[0] % 2 == 0 else p - k, :]
+            # mirror along every other axis as well: X[N0-k0, (N1-k1)%N1, ...] = conj X[k0, k1, ...]
+            mirrored = src
+            for ax in range(1, len(shape)):
+                a = len(shape) - ax          # numpy axis of logical axis `ax` (batch is numpy axis 0)
+                mirrored = np.roll(np.flip(mirrored, axis=a), 1, axis=a)
+            full[..., p - 1 + k, 0] = mirrored[..., 0]
+            full[..., p - 1 + k, 1] = -mirrored[..., 1]
+        y = oracle.c2c_ref_batch(full.reshape(-1), shape, batch, "inverse", "backward").reshape(batch, *reversed(shape), 2)[..., 0:1].copy()
+    y = y.reshape(batch, *reversed(shape), 1)
+    _zero_outside(y, shape, r["zero_pad"]["write"])
+    want = _extract(y, shape, vout, batch, 1, sentinel)
+    scale = max(1.0, float(np.max(np.abs(want))))
+    assert got.shape == want.shape and float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * scale, route

@@ -256,6 +256,48 @@ def test_strided_layout_whdcn(fft, dev, oracle):
     check(oracle, got, want, "whdcn lanes")
 
 
+def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle):
+    """views on the real transforms: the real side's window lives on the real domain, the spectrum side's on the packed one;
+    checked against the emu-tier numpy restatement (embed -> zero -> oracle -> zero -> extract)"""
+    from test_emu_ioview import _embed, _extract, _zero_outside
+    from mi355fft.layout import resolve_plan_options
+    shape, batch = [256, 6], 3
+    packed = [129, 6]
+    opts = {"type": "r2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "none",
+            "ioView": {"input": {"shape": [200, 5], "offset": [20, 1]}, "output": {"shape": [140, 6], "offset": [-4, 0], "clearOutside": True}},
+            "zeroPad": {"read": {"start": [30, 0], "end": [210, 6]}, "write": {"start": [0, 0], "end": [100, 6]}}}
+    r = resolve_plan_options(opts)
+    x = oracle.random_real_batch(200 * 5, batch, 9911).reshape(-1)
+    out_floats = 2 * 140 * 6 * batch
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
+    got, (route, _) = run_plan(fft, dev, opts, x, out_floats, out_init=sentinel)
+    assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
+    logical = _embed(x, shape, r["io_view"]["input"], batch, 1)
+    _zero_outside(logical, shape, r["zero_pad"]["read"])
+    cplx = np.zeros((batch, *reversed(shape), 2), np.float32)
+    cplx[..., 0] = logical[..., 0]
+    y = oracle.c2c_ref_batch(cplx.reshape(-1), shape, batch, "forward", "none").reshape(batch, *reversed(shape), 2)[..., :129, :].copy()
+    _zero_outside(y, packed, r["zero_pad"]["write"])
+    want = _extract(y, packed, r["io_view"]["output"], batch, 2, sentinel)
+    assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * max(1.0, float(np.max(np.abs(want))))
+    # c2r of a low-passed spectrum into a window of a larger real array
+    n = 4096
+    sig = oracle.random_real_batch(n, batch, 9912).reshape(-1)
+    spec = np.concatenate([oracle.r2c_ref_packed(sig[b * n:(b + 1) * n], n, "none") for b in range(batch)]).reshape(batch, n // 2 + 1, 2)
+    low = np.ascontiguousarray(spec[:, :300, :]).reshape(-1)
+    opts = {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward",
+            "ioView": {"input": {"shape": [300]}, "output": {"shape": [5000], "offset": [-100]}}}
+    sentinel = np.full(5000 * batch, 77.0, np.float32)
+    got, (route, _) = run_plan(fft, dev, opts, low, 5000 * batch, out_init=sentinel)
+    lp = spec.copy()
+    lp[:, 300:, :] = 0
+    want = sentinel.reshape(batch, 5000).copy()
+    for b in range(batch):
+        want[b, 100:100 + n] = oracle.c2r_ref_from_packed(lp[b].reshape(-1), n, "backward")
+    assert float(np.max(np.abs(got.astype(np.float64) - want.reshape(-1)))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), route
+    assert np.count_nonzero(got == 77.0) == 900 * batch
+
+
 def test_c2c_ioview_and_zeropad(fft, dev, oracle):
     """pad-in-read + embed-in-write (clearOutside) + range zeroing, checked against the emu-tier numpy restatement"""
     from test_emu_ioview import reference

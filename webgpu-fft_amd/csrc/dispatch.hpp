@@ -261,9 +261,9 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
     }
     case ST_ZERO_OUTSIDE: {
       ZeroOutsideArgs a{};
-      a.data = (cf*)ptr[0]; a.total = s.i[0]; a.per = s.i[1]; a.rank = (int)s.i[2];
+      a.data = ptr[0]; a.total = s.i[0]; a.per = s.i[1]; a.rank = (int)s.i[2];
       for (int d = 0; d < 8; ++d) { a.shape[d] = s.shape[d] ? s.shape[d] : 1; a.start[d] = s.sa[d]; a.end[d] = d < a.rank ? s.sb[d] : 1; }
-      l.launch(zero_outside_kernel, s.grid, 256u, 0u, a);
+      if (s.i[3]) l.launch(zero_outside_kernel<float>, s.grid, 256u, 0u, a); else l.launch(zero_outside_kernel<cf>, s.grid, 256u, 0u, a);
       return true;
     }
     case ST_ZERO:

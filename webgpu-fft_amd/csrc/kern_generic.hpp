@@ -290,12 +290,14 @@ static __global__ void __launch_bounds__(256) strided_copy_kernel(const StridedA
 
 // zeroPad stages (src/kernels/zero_pad.js:21-80): zero every logical element outside the box [start, end)
 struct ZeroOutsideArgs {
-  cf* data;
+  void* data;                      // complex (cf) or real (float) elements: zero_outside_kernel<ELEM>
   long long total, per;
   int rank;
   long long shape[8], start[8], end[8];
 };
+template <class ELEM = cf>
 static __global__ void __launch_bounds__(256) zero_outside_kernel(const ZeroOutsideArgs a) {
+  ELEM* data = static_cast<ELEM*>(a.data);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < a.total; g += (long long)gridDim.x * blockDim.x) {
     long long rem = g % a.per;
     bool inside = true;
@@ -304,7 +306,7 @@ static __global__ void __launch_bounds__(256) zero_outside_kernel(const ZeroOuts
       rem /= a.shape[i];
       inside = inside && c >= a.start[i] && c < a.end[i];
     }
-    if (!inside) { cf z = {0.0f, 0.0f}; a.data[g] = z; }
+    if (!inside) { ELEM z = {}; data[g] = z; }
   }
 }
 

@@ -617,31 +617,106 @@ bool view_region(const mi355fft_io_view& v, const int64_t* lshape, int rank, int
   return true;
 }
 
-void emit_zero_outside(Builder& b, PtrRef data, const mi355fft_zero_range& z, const int64_t* shape, int rank, int64_t batch) {
+void emit_zero_outside(Builder& b, PtrRef data, const mi355fft_zero_range& z, const int64_t* shape, int rank, int64_t batch, bool real = false) {
   Step& st = b.push(ST_ZERO_OUTSIDE);
-  st.p[0] = data;
+  st.p[0] = data; st.i[3] = real ? 1 : 0;
   const int64_t per = prodv(shape, rank);
   st.i[0] = per * batch; st.i[1] = per; st.i[2] = rank;
   for (int i = 0; i < rank; ++i) { st.shape[i] = shape[i]; st.sa[i] = z.start[i]; st.sb[i] = z.end[i]; }
   st.grid = b.generic_grid(st.i[0]);
 }
 
-int validate_views(const mi355fft_plan_desc& d, std::string& err) {
+int validate_views(const mi355fft_plan_desc& d, std::string& err, const int64_t* read_shape = nullptr, const int64_t* write_shape = nullptr) {
   for (const mi355fft_io_view* v : {&d.io_input, &d.io_output})
     if (v->enabled)
       for (int i = 0; i < d.rank; ++i)
         if (v->shape[i] <= 0) { err = "ioView shape must be an array of positive ints"; return MI355FFT_ERR_INVALID; }
   const char* names[2] = {"zeroPad.read", "zeroPad.write"};
+  const int64_t* shapes[2] = {read_shape ? read_shape : d.shape, write_shape ? write_shape : d.shape};   // r2c writes / c2r reads the PACKED domain
   int k = 0;
   for (const mi355fft_zero_range* z : {&d.zero_read, &d.zero_write}) {
     if (z->enabled)
       for (int i = 0; i < d.rank; ++i) {
-        if (z->start[i] < 0 || z->end[i] < 0 || z->start[i] > z->end[i] || z->end[i] > d.shape[i]) {
+        if (z->start[i] < 0 || z->end[i] < 0 || z->start[i] > z->end[i] || z->end[i] > shapes[k][i]) {
           err = std::string(names[k]) + ": need 0 <= start[" + std::to_string(i) + "] <= end[" + std::to_string(i) + "] <= shape[" + std::to_string(i) + "]";
           return MI355FFT_ERR_INVALID;
         }
       }
     ++k;
+  }
+  return MI355FFT_OK;
+}
+
+// ---- the two sides of an r2c / c2r plan (the same staging build_c2c does inline, for real or complex elements) ----
+// Input: strided layout, ioView.input (embed into the zero-filled logical domain) and zeroPad.read produce a dense logical
+// array in the workspace; a plain dense input is used where it lies.  `phys_n`: elements of one physical item.
+PtrRef stage_side_input(const mi355fft_plan_desc& d, Builder& b, PtrRef in, const int64_t* lshape, bool real, uint64_t& in_bytes) {
+  const int rank = d.rank;
+  const int64_t elem = real ? 4 : 8, n = prodv(lshape, rank);
+  const bool vin = d.io_input.enabled != 0;
+  const int64_t* ishape = vin ? d.io_input.shape : lshape;
+  const int64_t in_n = prodv(ishape, rank);
+  in_bytes = d.input.strided ? strided_extent_elems(d.input, ishape, rank, d.batch, 0) * elem : (uint64_t)in_n * d.batch * elem;
+  if (!(d.input.strided || vin || d.zero_read.enabled)) return in;
+  const PtrRef src = b.alloc_work((uint64_t)n * d.batch * elem);
+  if (vin) {
+    int64_t ext[8], ls[8], vs[8];
+    const bool any = view_region(d.io_input, lshape, rank, ext, ls, vs);
+    bool covers = any;
+    for (int i = 0; any && i < rank; ++i) covers = covers && ext[i] == lshape[i];
+    if (!covers) { Step& z = b.push(ST_ZERO); z.p[0] = src; z.i[0] = n * d.batch * (elem / 4); z.grid = b.generic_grid(z.i[0]); }
+    if (any) {
+      mi355fft_side_layout lay = d.input;
+      int64_t vstride = 1, poff = 0;
+      for (int i = 0; i < rank; ++i) { poff += vs[i] * (lay.strided ? lay.strides[i] : vstride); vstride *= ishape[i]; }
+      if (!lay.strided) { lay.strided = 1; int64_t st = 1; for (int i = 0; i < rank; ++i) { lay.strides[i] = st; st *= ishape[i]; } lay.offset_elements = 0; lay.batch_stride_elements = in_n; }
+      else if (lay.batch_stride_elements <= 0) lay.batch_stride_elements = in_n;
+      b.emit_strided(true, in, src, lay, ext, rank, d.batch, lshape, ls, n, poff, real);
+    }
+    b.ir.route += "embed ";
+  } else if (d.input.strided) {
+    b.emit_strided(true, in, src, d.input, lshape, rank, d.batch, lshape, nullptr, n, 0, real);
+    b.ir.route += "gather ";
+  } else {
+    Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = src; c.i[0] = n * d.batch * elem;
+  }
+  if (d.zero_read.enabled) { emit_zero_outside(b, src, d.zero_read, lshape, rank, d.batch, real); b.ir.route += "zero-read "; }
+  return src;
+}
+// Output: where the transform should write (the caller's buffer, or a dense logical staging array when a strided layout /
+// ioView.output follows), and the steps that finish the side afterwards.
+PtrRef side_output_target(const mi355fft_plan_desc& d, Builder& b, PtrRef out, const int64_t* lshape, bool real, uint64_t& out_bytes) {
+  const int rank = d.rank;
+  const int64_t elem = real ? 4 : 8;
+  const int64_t* oshape = d.io_output.enabled ? d.io_output.shape : lshape;
+  out_bytes = d.output.strided ? strided_extent_elems(d.output, oshape, rank, d.batch, 0) * elem : (uint64_t)prodv(oshape, rank) * d.batch * elem;
+  if (d.output.strided || d.io_output.enabled) return b.alloc_work((uint64_t)prodv(lshape, rank) * d.batch * elem);
+  return out;
+}
+int finish_side_output(const mi355fft_plan_desc& d, Builder& b, PtrRef out, PtrRef dst, const int64_t* lshape, bool real, std::string& err) {
+  const int rank = d.rank;
+  const int64_t elem = real ? 4 : 8, n = prodv(lshape, rank);
+  if (d.zero_write.enabled) { emit_zero_outside(b, dst, d.zero_write, lshape, rank, d.batch, real); b.ir.route += "zero-write "; }
+  if (d.io_output.enabled) {
+    const int64_t* oshape = d.io_output.shape;
+    const int64_t out_n = prodv(oshape, rank);
+    if (d.io_output.clear_outside) {
+      if (d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
+      Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * (elem / 4); z.grid = b.generic_grid(z.i[0]);
+    }
+    int64_t ext[8], ls[8], vs[8];
+    if (view_region(d.io_output, lshape, rank, ext, ls, vs)) {
+      mi355fft_side_layout lay = d.output;
+      int64_t vstride = 1, poff = 0;
+      for (int i = 0; i < rank; ++i) { poff += vs[i] * (lay.strided ? lay.strides[i] : vstride); vstride *= oshape[i]; }
+      if (!lay.strided) { lay.strided = 1; int64_t st = 1; for (int i = 0; i < rank; ++i) { lay.strides[i] = st; st *= oshape[i]; } lay.offset_elements = 0; lay.batch_stride_elements = out_n; }
+      else if (lay.batch_stride_elements <= 0) lay.batch_stride_elements = out_n;
+      b.emit_strided(false, out, dst, lay, ext, rank, d.batch, lshape, ls, n, poff, real);
+    }
+    b.ir.route += "extract ";
+  } else if (d.output.strided) {
+    b.emit_strided(false, out, dst, d.output, lshape, rank, d.batch, lshape, nullptr, n, 0, real);
+    b.ir.route += "scatter ";
   }
   return MI355FFT_OK;
 }
@@ -727,14 +802,13 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 // r2c along axis 0 (packed P = N/2+1 bins), then c2c along the remaining axes of the packed array
 int reject_views(const mi355fft_plan_desc& d, const char* what, std::string& err) {
   if (d.io_input.enabled || d.io_output.enabled || d.zero_read.enabled || d.zero_write.enabled) {
-    err = std::string("Unsupported: ioView / zeroPad on ") + what + " are not built yet (c2c only this round)";
+    err = std::string("Unsupported: ioView / zeroPad on ") + what + " are not built yet";
     return MI355FFT_ERR_UNSUPPORTED;
   }
   return MI355FFT_OK;
 }
 
 int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
-  if (int rv = reject_views(d, "r2c", err)) return rv;
   if (d.direction != MI355FFT_FORWARD) { err = "r2c supports direction:\"forward\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
   const int64_t N = d.shape[0], P = N / 2 + 1;
@@ -744,19 +818,11 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   int64_t pshape[MI355FFT_MAX_RANK];
   for (int i = 0; i < d.rank; ++i) pshape[i] = d.shape[i];
   pshape[0] = P;
-  const int64_t pn = prodv(pshape, d.rank);
-  PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
-  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, d.shape, d.rank, d.batch, 0) * 4 : (uint64_t)n * d.batch * 4;
-  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, pshape, d.rank, d.batch, 0) * 8 : (uint64_t)lines * P * 8;
-  // strided sides (layout.strides / layout.whdcn): real gather in front, complex scatter of the packed spectrum behind
-  const PtrRef user_out = out;
-  if (d.input.strided) {
-    const PtrRef dense_in = b.alloc_work((uint64_t)n * d.batch * 4);
-    b.emit_strided(true, in, dense_in, d.input, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0, true);
-    in = dense_in;
-    b.ir.route += "gather ";
-  }
-  if (d.output.strided) out = b.alloc_work((uint64_t)pn * d.batch * 8);
+  // ioView.input / zeroPad.read live on the real logical domain, ioView.output / zeroPad.write on the packed one (r2c.js:72-123)
+  if (int rv = validate_views(d, err, d.shape, pshape)) return rv;
+  const PtrRef user_out(BUF_OUTPUT, 0);
+  PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
+  PtrRef out = side_output_target(d, b, user_out, pshape, false, b.ir.out_bytes);
   if (b.emit_xcd_r2c(in, out, N, lines, scale)) {
     // one persistent launch: real four-step (kern_xcd_real.hpp)
   } else if (N % 2 == 0) {
@@ -786,15 +852,10 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     const int rc = b.emit_nd(out, out, pshape, d.rank, d.batch, false, 1.0f, err, 1);
     if (rc) return rc;
   }
-  if (d.output.strided) {
-    b.emit_strided(false, user_out, out, d.output, pshape, d.rank, d.batch, pshape, nullptr, pn, 0);
-    b.ir.route += "scatter ";
-  }
-  return MI355FFT_OK;
+  return finish_side_output(d, b, user_out, out, pshape, false, err);
 }
 
 int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
-  if (int rv = reject_views(d, "c2r", err)) return rv;
   if (d.direction != MI355FFT_INVERSE) { err = "c2r supports direction:\"inverse\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
   const int64_t N = d.shape[0], P = N / 2 + 1;
@@ -804,18 +865,11 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   int64_t pshape[MI355FFT_MAX_RANK];
   for (int i = 0; i < d.rank; ++i) pshape[i] = d.shape[i];
   pshape[0] = P;
-  const int64_t pn = prodv(pshape, d.rank);
-  PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0);
-  b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, pshape, d.rank, d.batch, 0) * 8 : (uint64_t)lines * P * 8;
-  b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, d.shape, d.rank, d.batch, 0) * 4 : (uint64_t)n * d.batch * 4;
-  const PtrRef user_out = out;
-  if (d.input.strided) {
-    const PtrRef dense_in = b.alloc_work((uint64_t)pn * d.batch * 8);
-    b.emit_strided(true, in, dense_in, d.input, pshape, d.rank, d.batch, pshape, nullptr, pn, 0);
-    in = dense_in;
-    b.ir.route += "gather ";
-  }
-  if (d.output.strided) out = b.alloc_work((uint64_t)n * d.batch * 4);
+  // ioView.input / zeroPad.read live on the packed domain, ioView.output / zeroPad.write on the real one (c2r.js:168-220)
+  if (int rv = validate_views(d, err, pshape, d.shape)) return rv;
+  const PtrRef user_out(BUF_OUTPUT, 0);
+  PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), pshape, false, b.ir.in_bytes);
+  PtrRef out = side_output_target(d, b, user_out, d.shape, true, b.ir.out_bytes);
   PtrRef packed = in;
   if (d.rank > 1) {
     // inverse c2c over axes 1.. of the packed spectrum; the caller's input is not modified
@@ -854,10 +908,7 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     r.grid = b.generic_grid(lines * N);
     b.ir.route += "c2r-full ";
   }
-  if (d.output.strided) {
-    b.emit_strided(false, user_out, out, d.output, d.shape, d.rank, d.batch, d.shape, nullptr, n, 0, true);
-    b.ir.route += "scatter ";
-  }
+  if (int rv = finish_side_output(d, b, user_out, out, d.shape, true, err)) return rv;
   return MI355FFT_OK;
 }
 

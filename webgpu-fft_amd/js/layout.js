@@ -312,10 +312,19 @@ export function resolvePlanOptions(opts) {
   const precision = dflt(opts.precision, "f32");
   assertOneOf(precision, ["f32", "f16-storage"], "precision");
   if (precision !== "f32") throw new Error('Unsupported: precision "f16-storage" is outside the MI355X hot path (f32 only)');
-  const ioView = normalizeIoView(rank, shape, opts.ioView);
-  const zeroPad = normalizeZeroPad(rank, shape, opts.zeroPad);
-  if (type !== "c2c" && (ioView.input || ioView.output || zeroPad.read || zeroPad.write)) {
-    throw new Error("Unsupported: ioView / zeroPad on " + type + " are not built yet (c2c only; SURVEY.md section 8f rank 2)");
+  // logical domains of the two sides: r2c writes / c2r reads the PACKED spectrum (r2c.js:72-123, c2r.js:168-220)
+  const packedShape = [Math.floor(shape[0] / 2) + 1].concat(shape.slice(1));
+  const inLogical = type === "c2r" ? packedShape : shape;
+  const outLogical = type === "r2c" ? packedShape : shape;
+  const ivIn = opts.ioView || {};
+  const zpIn = opts.zeroPad;
+  if (zpIn !== undefined && zpIn !== null && typeof zpIn !== "object") throw new Error("zeroPad must be an object with optional read/write stage configs");
+  const ioView = { input: normalizeIoView(rank, inLogical, { input: ivIn.input }).input,
+                   output: normalizeIoView(rank, outLogical, { output: ivIn.output }).output };
+  const zeroPad = { read: normalizeZeroPad(rank, inLogical, { read: (zpIn || {}).read }).read,
+                    write: normalizeZeroPad(rank, outLogical, { write: (zpIn || {}).write }).write };
+  if (type === "fftconv" && (ioView.input || ioView.output || zeroPad.read || zeroPad.write)) {
+    throw new Error("Unsupported: ioView / zeroPad on fftconv are not built yet (SURVEY.md section 8f rank 2)");
   }
   const inPlace = !!opts.inPlace;
   const meta = { type, shape, rank, batch, inPlace, ioView, zeroPad };
@@ -380,8 +389,8 @@ export function resolvePlanOptions(opts) {
   if (type === "c2r" && direction !== "inverse") throw new Error('c2r supports direction:"inverse" only');
   if (inPlace && type !== "c2c") throw new Error("inPlace=true is supported only on c2c");
   const packed = [Math.floor(shape[0] / 2) + 1].concat(shape.slice(1));
-  const inShape = type === "c2r" ? packed : (ioView.input ? ioView.input.shape : shape);
-  const outShape = type === "r2c" ? packed : (ioView.output ? ioView.output.shape : shape);
+  const inShape = ioView.input ? ioView.input.shape : (type === "c2r" ? packed : shape);
+  const outShape = ioView.output ? ioView.output.shape : (type === "r2c" ? packed : shape);
   const sides = resolveLayoutSemantics(layout, rank, inShape, outShape);
   desc.direction = DIRECTION_CODE[direction];
   desc.normalize = NORMALIZE_CODE[normalize];

@@ -49,6 +49,23 @@ test("option validation messages", () => {
   for (const [opts, re] of bad) assertThrows(() => fft.resolvePlanOptions(opts), re, JSON.stringify(opts));
 });
 
+test("ioView / zeroPad on r2c and c2r resolve against the real and the packed domain", () => {
+  // r2c: the input view lives on the real domain (16), the output view and zeroPad.write on the packed one (9 bins)
+  const a = fft.resolvePlanOptions({ type: "r2c", shape: [16], batch: 2, direction: "forward",
+                                 ioView: { input: { shape: [10], placement: "center" }, output: { shape: [5], offset: [2] } },
+                                 zeroPad: { write: { start: [0], end: [6] } } });
+  assert(deepEqual(a.meta.ioView.input, { shape: [10], offset: [3], clearOutside: false }));
+  assert(deepEqual(a.meta.ioView.output, { shape: [5], offset: [2], clearOutside: false }));
+  assert(deepEqual(a.meta.zeroPad, { read: null, write: { start: [0], end: [6] } }));
+  assertThrows(() => fft.resolvePlanOptions({ type: "r2c", shape: [16], direction: "forward", zeroPad: { write: { start: [0], end: [10] } } }),
+               /zeroPad\.write\.end\[0\] must be <= shape\[0\] \(9\); got 10/, "r2c zeroPad.write");
+  // c2r: mirrored — a full-domain packed view is a no-op, the real side takes the window
+  const c = fft.resolvePlanOptions({ type: "c2r", shape: [16], direction: "inverse", ioView: { input: { shape: [9] }, output: { shape: [24], placement: "center", clearOutside: true } } });
+  assert(c.meta.ioView.input === null);
+  assert(deepEqual(c.meta.ioView.output, { shape: [24], offset: [-4], clearOutside: true }));
+  assertThrows(() => fft.resolvePlanOptions({ type: "fftconv", shape: [16], fftConv: { kernelCount: 1 }, zeroPad: { read: { start: [1], end: [16] } } }), /Unsupported: ioView \/ zeroPad on fftconv/, "fftconv views");
+});
+
 test("normalizeScaleFactor matches the reference bit for bit", () => {
   for (const r of cases.normalize_scale.rows) {
     const want = Buffer.from(r.value, "hex").readDoubleLE(0);

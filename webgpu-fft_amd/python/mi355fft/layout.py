@@ -405,10 +405,20 @@ def resolve_plan_options(opts):
     _assert_one_of(precision, ("f32", "f16-storage"), "precision")
     if precision != "f32":
         raise NotImplementedError('precision "f16-storage" is outside the MI355X hot path (f32 only)')
-    io_view = normalize_io_view(rank, shape, opts.get("ioView"))
-    zero_pad = normalize_zero_pad(rank, shape, opts.get("zeroPad"))
-    if typ != "c2c" and (io_view["input"] or io_view["output"] or zero_pad["read"] or zero_pad["write"]):
-        raise NotImplementedError(f"ioView / zeroPad on {typ} are not built yet (c2c only; SURVEY.md section 8f rank 2)")
+    # logical domains of the two sides: r2c writes / c2r reads the PACKED spectrum (r2c.js:72-123, c2r.js:168-220)
+    packed_shape = [shape[0] // 2 + 1] + shape[1:]
+    in_logical = packed_shape if typ == "c2r" else shape
+    out_logical = packed_shape if typ == "r2c" else shape
+    iv = opts.get("ioView") or {}
+    zp = opts.get("zeroPad")
+    io_view = {"input": normalize_io_view(rank, in_logical, {"input": iv.get("input")})["input"],
+               "output": normalize_io_view(rank, out_logical, {"output": iv.get("output")})["output"]}
+    if zp is not None and not isinstance(zp, dict):
+        raise ValueError("zeroPad must be an object with optional read/write stage configs")
+    zero_pad = {"read": normalize_zero_pad(rank, in_logical, {"read": (zp or {}).get("read")})["read"],
+                "write": normalize_zero_pad(rank, out_logical, {"write": (zp or {}).get("write")})["write"]}
+    if typ == "fftconv" and (io_view["input"] or io_view["output"] or zero_pad["read"] or zero_pad["write"]):
+        raise NotImplementedError("ioView / zeroPad on fftconv are not built yet (SURVEY.md section 8f rank 2)")
     in_place = bool(opts.get("inPlace", False))
     normalize = opts.get("normalize", "none")
     out = {"type": typ, "shape": shape, "batch": batch, "inPlace": in_place, "normalize": normalize, "conv": None,
@@ -466,8 +476,8 @@ def resolve_plan_options(opts):
     if in_place and typ != "c2c":
         raise ValueError("inPlace=true is supported only on c2c")
     packed = [shape[0] // 2 + 1] + shape[1:]
-    in_shape = packed if typ == "c2r" else (io_view["input"]["shape"] if io_view["input"] else shape)
-    out_shape = packed if typ == "r2c" else (io_view["output"]["shape"] if io_view["output"] else shape)
+    in_shape = io_view["input"]["shape"] if io_view["input"] else (packed if typ == "c2r" else shape)
+    out_shape = io_view["output"]["shape"] if io_view["output"] else (packed if typ == "r2c" else shape)
     inp, outl = resolve_layout_semantics(layout, rank, in_shape, out_shape)
     out.update({"direction": direction, "input_layout": inp, "output_layout": outl})
     return out
