@@ -100,12 +100,17 @@ typedef struct mi355fft_plan_desc {
   int32_t conv_output_layout;      /* dense output: [kernel][batch][logical] or [batch][kernel][logical] */
   int64_t conv_kernel_shape[MI355FFT_MAX_RANK]; /* all 0 => same as shape */
   int64_t conv_output_kernel_stride_elements;   /* strided output: lane step per kernel (fftconv.js:868-871) */
-  /* c2c only this round: padding / embedding / range zeroing (docs/API.md "ioView", "zeroPad").  When an ioView side is
-   * enabled, that side's layout (dense or strided) describes the VIEW's physical shape. */
+  /* c2c, r2c, c2r: padding / embedding / range zeroing (docs/API.md "ioView", "zeroPad").  When an ioView side is enabled,
+   * that side's layout (dense or strided) describes the VIEW's physical shape; for r2c the output side (for c2r the input
+   * side) views and ranges live on the packed domain (shape[0]/2+1 bins along axis 0). */
   mi355fft_io_view io_input;
   mi355fft_io_view io_output;
   mi355fft_zero_range zero_read;
   mi355fft_zero_range zero_write;
+  /* c2c only: createFftPlan({axes}) (plan.js:1307,1335-1339) — bit a set => axis a is transformed; 0 => all axes.  The
+   * normalisation factor still uses prod(shape) over ALL axes, as the reference's does (plan.js:1334,1382). */
+  uint32_t axes_mask;
+  uint32_t reserved2;
 } mi355fft_plan_desc;
 
 /* plan.exec(commandEncoder, {input, output?, temp?, inputOffsetBytes, outputOffsetBytes, kernel?})

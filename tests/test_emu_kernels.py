@@ -105,6 +105,34 @@ def test_c2c_nd_mixed_radix_lines(oracle, shape, expect):
         check(got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} {route}", 1e-5)
 
 
+def _fft_axes_ref(oracle, x, shape, batch, axes, direction, scale):
+    """oracle 1-D transforms along the chosen axes only (axis 0 fastest = last numpy axis before re/im)"""
+    rank = len(shape)
+    a = x.reshape(batch, *reversed(shape), 2).copy()
+    for ax in sorted(set(axes)):
+        npax = rank - ax                           # numpy axis of logical axis ax (batch is numpy axis 0)
+        m = np.moveaxis(a, npax, -2)
+        lines = np.ascontiguousarray(m).reshape(-1, shape[ax], 2)
+        out = oracle.c2c_ref_batch(lines.reshape(-1), [shape[ax]], lines.shape[0], direction, "none").reshape(m.shape)
+        a = np.moveaxis(out, -2, npax)
+    return (np.ascontiguousarray(a) * np.float32(scale)).reshape(-1)
+
+
+@pytest.mark.parametrize("shape,axes", [([16, 8], [0]), ([16, 8], [1]), ([8, 4, 6], [0, 2]), ([8, 4, 6], [1]), ([32, 3], [1, 0])])
+def test_c2c_axes_subset(oracle, shape, axes):
+    """createFftPlan({axes}) (plan.js:1335-1339): only the listed axes are transformed; the unitary factor keeps prod(shape)"""
+    batch = 2
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0xA7E5 + n).reshape(-1)
+    for direction, norm, scale in (("forward", "none", 1.0), ("inverse", "backward", 1.0 / n), ("forward", "unitary", 1.0 / np.sqrt(n))):
+        desc = _abi.make_desc("c2c", shape, batch, direction, norm, axes=axes)
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        check(got, _fft_axes_ref(oracle, x, shape, batch, axes, direction, scale), f"axes={axes} {direction} {route}", 2e-6)
+    desc = _abi.make_desc("c2c", shape, batch, "forward", "none", in_place=True, axes=axes)
+    got, _, _ = emu.run_plan(desc, x, x.size)
+    check(got, _fft_axes_ref(oracle, x, shape, batch, axes, "forward", 1.0), f"axes={axes} in place", 2e-6)
+
+
 def test_c2c_generic_route_matches_lines_route(oracle):
     x = oracle.random_complex_batch(1024, 2, 3).reshape(-1)
     desc = _abi.make_desc("c2c", [1024], 2, "forward", "none")

@@ -89,7 +89,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
     _abi.declare(L)
     assert L.mi355fft_abi_version() == 1
-    assert ctypes.sizeof(_abi.PlanDesc) == 904 and ctypes.sizeof(_abi.ExecArgs) == 64
+    assert ctypes.sizeof(_abi.PlanDesc) == 912 and ctypes.sizeof(_abi.ExecArgs) == 64
 
 
 def test_no_cpu_fallback_without_a_gpu():

@@ -527,18 +527,20 @@ struct Builder {
   }
 
   // all axes of a dense [batch][shape] complex array, src -> dst
+  // axes_mask: bit a set => axis a is transformed (createFftPlan({axes})); 0 => every axis from first_axis on
   int emit_nd(PtrRef src, PtrRef dst, const int64_t* shape, int rank, int64_t batch, bool inverse, float scale, std::string& err,
-              int first_axis = 0) {
+              int first_axis = 0, uint32_t axes_mask = 0) {
     PtrRef cur = src;
     int64_t S = 1;
     for (int a = 0; a < first_axis; ++a) S *= shape[a];
     const int64_t total = prodv(shape, rank);
     bool any = false;
     int last_axis = -1;
-    for (int a = first_axis; a < rank; ++a) if (shape[a] > 1) last_axis = a;
+    const auto wanted = [&](int a) { return axes_mask == 0 || ((axes_mask >> a) & 1u); };
+    for (int a = first_axis; a < rank; ++a) if (shape[a] > 1 && wanted(a)) last_axis = a;
     for (int a = first_axis; a < rank; ++a) {
       const int64_t N = shape[a];
-      if (N > 1) {
+      if (N > 1 && wanted(a)) {
         const int64_t outer = batch * (total / (S * N));
         const int rc = emit_axis(cur, dst, N, S, outer, inverse, a == last_axis ? scale : 1.0f, err);
         if (rc) return rc;
@@ -772,7 +774,8 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   const bool stage_out = d.output.strided || vout;
   PtrRef dst = out;
   if (stage_out) dst = stage_in ? src : b.alloc_work((uint64_t)n * d.batch * 8);
-  rc = b.emit_nd(src, dst, d.shape, rank, d.batch, inverse, scale, err);
+  if (d.axes_mask >> rank) { err = "Invalid axis in axes for rank " + std::to_string(rank); return MI355FFT_ERR_INVALID; }
+  rc = b.emit_nd(src, dst, d.shape, rank, d.batch, inverse, scale, err, 0, d.axes_mask);
   if (rc) return rc;
   if (d.zero_write.enabled) { emit_zero_outside(b, dst, d.zero_write, d.shape, rank, d.batch); b.ir.route += "zero-write "; }
 

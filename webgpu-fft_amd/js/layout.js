@@ -333,6 +333,16 @@ export function resolvePlanOptions(opts) {
   if (ioView.output) desc.ioOutput = Object.assign({}, ioView.output, { clearOutside: ioView.output.clearOutside ? 1 : 0 });
   if (zeroPad.read) desc.zeroRead = zeroPad.read;
   if (zeroPad.write) desc.zeroWrite = zeroPad.write;
+  if (opts.axes !== undefined && opts.axes !== null) {      // createFftPlan({axes}) forwards its subset here (c2c only)
+    if (type !== "c2c") throw new Error("axes is a createFftPlan (c2c) option");
+    let mask = 0;
+    for (const axis of opts.axes) {
+      if (!Number.isInteger(axis) || axis < 0 || axis >= rank) throw new Error("Invalid axis " + axis + " for rank " + rank);
+      mask |= 1 << axis;
+    }
+    desc.axesMask = mask;
+    meta.axes = opts.axes.slice();
+  }
 
   if (type === "fftconv") {
     const fc = opts.fftConv || {};

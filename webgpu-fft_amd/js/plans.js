@@ -144,10 +144,12 @@ export class FftPlan extends NativePlanBase {
     if (direction !== "forward" && direction !== "inverse") throw new Error('direction must be "forward" or "inverse"; got ' + JSON.stringify(direction));
     const normalize = o.normalize === undefined ? "none" : o.normalize;
     if (!["none", "backward", "unitary"].includes(normalize)) throw new Error("normalize must be none|backward|unitary; got " + JSON.stringify(normalize));
+    // axes: null => every axis; otherwise the listed axes only (plan.js:1335-1339; the scale factor keeps prod(shape))
+    this.axes = null;
     if (o.axes !== undefined && o.axes !== null) {
-      const all = shape.map((_, i) => i);
-      const ok = Array.isArray(o.axes) && o.axes.length === all.length && o.axes.slice().sort((a, b) => a - b).every((v, i) => v === all[i]);
-      if (!ok) throw new Error("Unsupported: createFftPlan axes subsets are not built yet (all axes are transformed)");
+      if (!Array.isArray(o.axes) || o.axes.length === 0) throw new Error("axes must be null or a non-empty array");
+      for (const axis of o.axes) if (!Number.isInteger(axis) || axis < 0 || axis >= shape.length) throw new Error("Invalid axis " + axis + " for rank " + shape.length);
+      this.axes = o.axes.slice();
     }
     this.shape = shape.slice();
     this.direction = direction;
@@ -158,7 +160,7 @@ export class FftPlan extends NativePlanBase {
   _planFor(batch) {
     let p = this._plans.get(batch);
     if (!p) {
-      p = new Plan(this.device, { type: "c2c", shape: this.shape, batch, direction: this.direction, normalize: this.normalize, inPlace: this.inPlace });
+      p = new Plan(this.device, { type: "c2c", shape: this.shape, batch, direction: this.direction, normalize: this.normalize, inPlace: this.inPlace, axes: this.axes });
       this._plans.set(batch, p);
     }
     return p;

@@ -96,6 +96,32 @@ test("createFftPlan low-level API: batch at exec, in-place vs out-of-place (test
   a.destroy(); b.destroy();
 });
 
+test("createFftPlan axes subsets (plan.js:1335-1339): axis 1 of a 16x8 array only", async () => {
+  const dev = await ensureDevice();
+  const N0 = 16, N1 = 8, batch = 3;
+  const input = orc.randomComplexInterleaved(N0 * N1 * batch, orc.mulberry32(77));
+  // reference: for every (batch, i0) the line over i1 (stride N0) through the 1-D oracle
+  const want = new Float32Array(input.length);
+  for (let b = 0; b < batch; ++b) {
+    for (let i0 = 0; i0 < N0; ++i0) {
+      const line = new Float32Array(2 * N1);
+      for (let i1 = 0; i1 < N1; ++i1) { const p = 2 * (b * N0 * N1 + i1 * N0 + i0); line[2 * i1] = input[p]; line[2 * i1 + 1] = input[p + 1]; }
+      const y = orc.c2cRefBatch(line, [N1], 1, "forward", "none");
+      for (let i1 = 0; i1 < N1; ++i1) { const p = 2 * (b * N0 * N1 + i1 * N0 + i0); want[p] = y[2 * i1]; want[p + 1] = y[2 * i1 + 1]; }
+    }
+  }
+  const a = fft.uploadComplex(dev, input);
+  const o = dev.createBuffer({ size: input.byteLength, usage: 0 });
+  const p = fft.createFftPlan(dev, { shape: [N0, N1], direction: "forward", axes: [1] });
+  const enc = dev.createCommandEncoder();
+  p.exec(enc, { input: a, output: o, batch });
+  dev.queue.submit([enc.finish()]);
+  check(await fft.downloadComplex(dev, o, N0 * N1 * batch), want, 1e-4, 1e-4, "FftPlan axes=[1]");
+  assertThrows(() => fft.createFftPlan(dev, { shape: [N0, N1], direction: "forward", axes: [2] }), /Invalid axis 2 for rank 2/);
+  assertThrows(() => fft.createFftPlan(dev, { shape: [N0, N1], direction: "forward", axes: [] }), /axes must be null or a non-empty array/);
+  p.destroy(); a.destroy(); o.destroy();
+});
+
 test("r2c / c2r N=16, 1024 (complete.suite.js:1776-1813 shape) + golden fixtures", async () => {
   const dev = await ensureDevice();
   for (const N of [16, 1024]) {

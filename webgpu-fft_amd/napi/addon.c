@@ -336,6 +336,7 @@ static napi_value js_plan_create(napi_env env, napi_callback_info info) {
   fill_view(env, o, "ioOutput", &d.io_output);
   fill_range(env, o, "zeroRead", &d.zero_read);
   fill_range(env, o, "zeroWrite", &d.zero_write);
+  d.axes_mask = (uint32_t)prop_i64(env, o, "axesMask", 0);
   mi355fft_plan* p = NULL;
   MI_CALL(env, mi355fft_plan_create((mi355fft_device*)get_ext(env, a[0]), &d, &p));
   return make_ext(env, p);

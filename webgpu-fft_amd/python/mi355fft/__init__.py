@@ -174,7 +174,7 @@ class Plan:
         self.type = resolved["type"]
         self._desc = _abi.make_desc(resolved["type"], resolved["shape"], resolved["batch"], resolved["direction"], resolved["normalize"],
                                     resolved["inPlace"], resolved["input_layout"], resolved["output_layout"], resolved.get("conv"),
-                                    resolved.get("io_view"), resolved.get("zero_pad"))
+                                    resolved.get("io_view"), resolved.get("zero_pad"), resolved.get("axes"))
         h = ctypes.c_void_p()
         _chk(lib().mi355fft_plan_create(device._h, ctypes.byref(self._desc), ctypes.byref(h)))
         self._h = h

@@ -61,6 +61,8 @@ class PlanDesc(ctypes.Structure):
         ("io_output", IoView),
         ("zero_read", ZeroRange),
         ("zero_write", ZeroRange),
+        ("axes_mask", ctypes.c_uint32),
+        ("reserved2", ctypes.c_uint32),
     ]
 
 
@@ -112,7 +114,7 @@ def _fill_range(dst, spec, rank):
 
 
 def make_desc(type, shape, batch=1, direction="forward", normalize="none", in_place=False, input_layout=None, output_layout=None,
-              conv=None, io_view=None, zero_pad=None):
+              conv=None, io_view=None, zero_pad=None, axes=None):
     """Build a PlanDesc from already-RESOLVED options (layout resolution lives in mi355fft.plans)."""
     d = PlanDesc()
     d.struct_size = ctypes.sizeof(PlanDesc)
@@ -144,6 +146,9 @@ def make_desc(type, shape, batch=1, direction="forward", normalize="none", in_pl
     if zero_pad:
         _fill_range(d.zero_read, zero_pad.get("read"), d.rank)
         _fill_range(d.zero_write, zero_pad.get("write"), d.rank)
+    if axes is not None:
+        for a in axes:
+            d.axes_mask |= 1 << int(a)
     return d
 
 

@@ -421,8 +421,18 @@ def resolve_plan_options(opts):
         raise NotImplementedError("ioView / zeroPad on fftconv are not built yet (SURVEY.md section 8f rank 2)")
     in_place = bool(opts.get("inPlace", False))
     normalize = opts.get("normalize", "none")
+    axes = opts.get("axes")            # createFftPlan({axes}) (plan.js:1335-1339): c2c only; the scale factor keeps prod(shape)
+    if axes is not None:
+        if typ != "c2c":
+            raise ValueError("axes is a createFftPlan (c2c) option")
+        if not isinstance(axes, (list, tuple)) or len(axes) == 0:
+            raise ValueError("axes must be null or a non-empty array")
+        for a in axes:
+            if not _is_int(a) or a < 0 or a >= rank:
+                raise ValueError(f"Invalid axis {a} for rank {rank}")
+        axes = list(axes)
     out = {"type": typ, "shape": shape, "batch": batch, "inPlace": in_place, "normalize": normalize, "conv": None,
-           "io_view": io_view, "zero_pad": zero_pad}
+           "io_view": io_view, "zero_pad": zero_pad, "axes": axes}
 
     if typ == "fftconv":
         fc = opts.get("fftConv") or {}
