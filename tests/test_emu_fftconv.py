@@ -15,7 +15,7 @@ from mi355fft.layout import createFftConvKernelMajorChannelLanePreset, resolve_p
 def _desc(opts):
     r = resolve_plan_options(opts)
     return _abi.make_desc(r["type"], r["shape"], r["batch"], r["direction"], r["normalize"], r["inPlace"], r["input_layout"],
-                          r["output_layout"], r["conv"]), r
+                          r["output_layout"], r["conv"], None, r["zero_pad"]), r
 
 
 def _close(got, want, atol, rtol, what):
@@ -151,3 +151,51 @@ def test_fftconv_fused_matches_composed_route_and_oracle(oracle, n, K, batch, mo
         want = want.transpose(1, 0, 2)
     _close(fused, want.reshape(-1), 4e-3, 4e-3, f"fused N={n} K={K}")
     assert oracle.rel_l2(fused, want.reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("shape,kshape,boundary,zero_pad", [
+    ([16], None, "circular", {"read": {"start": [2], "end": [12]}, "write": {"start": [4], "end": [16]}}),
+    ([64], [5], "circular", {"read": {"start": [8], "end": [60]}}),                      # would take the fused kernel without zeroPad
+    ([12, 5], [3, 2], "linear-same", {"read": {"start": [1, 0], "end": [10, 5]}, "write": {"start": [2, 1], "end": [13, 5]}}),
+    ([10], [4], "linear-valid", {"write": {"start": [0], "end": [8]}}),
+    ([10], [4], "linear-full", {"write": {"start": [3], "end": [11]}}),
+])
+def test_fftconv_zero_pad(oracle, shape, kshape, boundary, zero_pad):
+    """zeroPad ranges live on the FFT domain (fftconv.js:353,386): read zeroes the embedded data before the forward
+    transform, write zeroes the inverse transform before the crop"""
+    batch, K, rank = 2, 2, len(shape)
+    ks = kshape or shape
+    n, kn = int(np.prod(shape)), int(np.prod(ks))
+    x = oracle.random_complex_interleaved(n * batch, 5150 + n)
+    kern = oracle.random_complex_interleaved(kn * K, 5151 + n)
+    desc, r = _desc({"type": "fftconv", "shape": shape, "batch": batch, "zeroPad": zero_pad,
+                     "fftConv": {"boundary": boundary, "kernelCount": K, "kernelShape": kshape}})
+    zr, zw = r["zero_pad"]["read"], r["zero_pad"]["write"]
+    if boundary == "circular":
+        oshape, ooff = list(shape), [0] * rank
+    elif boundary == "linear-full":
+        oshape, ooff = [s + k - 1 for s, k in zip(shape, ks)], [0] * rank
+    elif boundary == "linear-same":
+        oshape, ooff = list(shape), [(k - 1) // 2 for k in ks]
+    else:
+        oshape, ooff = [s - k + 1 for s, k in zip(shape, ks)], [k - 1 for k in ks]
+    xin = x.reshape(batch, *reversed(shape), 2).copy()
+    if zr:      # the data sits at the origin of the domain: domain coordinates = input coordinates
+        keep = np.zeros(tuple(reversed(shape)), bool)
+        keep[tuple(slice(zr["start"][d], min(zr["end"][d], shape[d])) for d in reversed(range(rank)))] = True
+        xin[:, ~keep] = 0
+    on = int(np.prod(oshape))
+    want = np.zeros((K, batch, *reversed(oshape), 2), np.float32)
+    for k in range(K):
+        y, _ = oracle.fftconv_ref(xin.reshape(-1), kern[2 * k * kn:2 * (k + 1) * kn], shape, batch, "convolution", boundary, kshape)
+        want[k] = np.asarray(y, np.float32).reshape(batch, *reversed(oshape), 2)
+    if zw:      # output coordinate o is domain coordinate o + ooff
+        keep = np.zeros(tuple(reversed(oshape)), bool)
+        sl = tuple(slice(max(0, zw["start"][d] - ooff[d]), max(0, min(oshape[d], zw["end"][d] - ooff[d]))) for d in reversed(range(rank)))
+        keep[sl] = True
+        want[:, :, ~keep] = 0
+    got, route, _ = emu.run_plan(desc, x, 2 * on * K * batch, kernel=kern)
+    assert not route.startswith("fftconv-fused")
+    assert ("zero-read" in route) == bool(zr) and ("zero-write" in route) == bool(zw), route
+    _close(got, want.reshape(-1), 4e-3, 4e-3, f"fftconv zeroPad {shape} {boundary}")
+    assert oracle.rel_l2(got, want.reshape(-1)) < 1e-5

@@ -109,8 +109,9 @@ def test_view_validation_messages():
         with pytest.raises(ValueError) as e:
             resolve_plan_options(dict({"type": "c2c", "shape": [8, 4], "direction": "forward"}, **extra))
         assert frag in str(e.value)
-    with pytest.raises(NotImplementedError):
-        resolve_plan_options({"type": "fftconv", "shape": [8], "fftConv": {"kernelCount": 1}, "zeroPad": {"read": {"start": [1], "end": [8]}}})
+    with pytest.raises(ValueError) as e:    # fftconv takes zeroPad (on its FFT domain) but no ioView
+        resolve_plan_options({"type": "fftconv", "shape": [8], "fftConv": {"kernelCount": 1}, "ioView": {"input": {"shape": [4]}}})
+    assert "ioView is not an fftconv option" in str(e.value)
     with pytest.raises(ValueError) as e:    # r2c writes the packed domain: shape[0] // 2 + 1 = 5 bins
         resolve_plan_options({"type": "r2c", "shape": [8], "direction": "forward", "zeroPad": {"write": {"start": [0], "end": [6]}}})
     assert "zeroPad.write.end[0] must be <= shape[0] (5); got 6" in str(e.value)

@@ -803,14 +803,6 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 }
 
 // r2c along axis 0 (packed P = N/2+1 bins), then c2c along the remaining axes of the packed array
-int reject_views(const mi355fft_plan_desc& d, const char* what, std::string& err) {
-  if (d.io_input.enabled || d.io_output.enabled || d.zero_read.enabled || d.zero_write.enabled) {
-    err = std::string("Unsupported: ioView / zeroPad on ") + what + " are not built yet";
-    return MI355FFT_ERR_UNSUPPORTED;
-  }
-  return MI355FFT_OK;
-}
-
 int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (d.direction != MI355FFT_FORWARD) { err = "r2c supports direction:\"forward\" only"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "inPlace=true is supported only on c2c"; return MI355FFT_ERR_INVALID; }
@@ -918,7 +910,7 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 // y_k = IFFT( FFT(x) .* (conj?)FFT(h_k) ) / Nfft, cropped per boundary, written per output layout / lanes
 // (runtime/plans/fftconv.js:308-709, exec :1415-1712; reference semantics: src/utils/math.js:469-603)
 int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
-  if (int rv = reject_views(d, "fftconv", err)) return rv;
+  if (d.io_input.enabled || d.io_output.enabled) { err = "ioView is not an fftconv option"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "fftconv inPlace=true is not supported in current implementation"; return MI355FFT_ERR_INVALID; }
   if (d.conv_mode != MI355FFT_CONVOLUTION && d.conv_mode != MI355FFT_CORRELATION) { err = "fftConv.mode must be one of \"convolution\", \"correlation\""; return MI355FFT_ERR_INVALID; }
   if (d.conv_boundary < 0 || d.conv_boundary > 3) { err = "fftConv.boundary must be one of \"circular\", \"linear-full\", \"linear-same\", \"linear-valid\""; return MI355FFT_ERR_INVALID; }
@@ -944,6 +936,10 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       }
     }
   }
+  // zeroPad ranges live on the FFT domain: read = the embedded data before the forward transform, write = the inverse
+  // transform before the crop (fftconv.js:386,542,565)
+  if (int rv = validate_views(d, err, fs, fs)) return rv;
+  const bool zpad = d.zero_read.enabled || d.zero_write.enabled;
   const int64_t inN = prodv(d.shape, rank), kN = prodv(ks, rank), fN = prodv(fs, rank), oN = prodv(os, rank);
   PtrRef in(BUF_INPUT, 0), out(BUF_OUTPUT, 0), kern(BUF_KERNEL, 0);
   b.ir.kernel_bytes = (uint64_t)K * kN * 8;
@@ -955,7 +951,7 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   } else b.ir.out_bytes = (uint64_t)K * B * oN * 8;
 
   // small 1-D circular problems: one launch, one workgroup per batch entry (kern_fftconv.hpp)
-  if (!b.opt.force_generic && rank == 1 && d.conv_boundary == MI355FFT_CIRCULAR && K <= 15) {
+  if (!b.opt.force_generic && !zpad && rank == 1 && d.conv_boundary == MI355FFT_CIRCULAR && K <= 15) {
     const ConvKernelMeta* cm = nullptr;
     for (const auto& m : conv_kernel_registry())
       if (m.N == fN && m.TL >= K + 1 && (!cm || m.TL < cm->TL)) cm = &m;
@@ -999,7 +995,10 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   PtrRef xf = b.alloc_work((uint64_t)B * fN * 8);
   if (embed) { Step& z = b.push(ST_ZERO); z.p[0] = xf; z.i[0] = B * fN * 2; z.grid = b.generic_grid(B * fN * 2); }
   if (embed || d.input.strided) b.emit_strided(true, in, xf, d.input, d.shape, rank, B, fs, zero, fN, 0);
-  rc = b.emit_nd((embed || d.input.strided) ? xf : in, xf, fs, rank, B, false, 1.0f, err);
+  else if (d.zero_read.enabled) { Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = xf; c.i[0] = B * fN * 8; }
+  const bool staged = embed || d.input.strided || d.zero_read.enabled;
+  if (d.zero_read.enabled) { emit_zero_outside(b, xf, d.zero_read, fs, rank, B); b.ir.route += "zero-read "; }
+  rc = b.emit_nd(staged ? xf : in, xf, fs, rank, B, false, 1.0f, err);
   if (rc) return rc;
   // 3. per kernel: product, inverse transform scaled by 1/Nfft, crop + place
   PtrRef y = b.alloc_work((uint64_t)B * fN * 8);
@@ -1013,10 +1012,12 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     if (direct_out && d.conv_output_layout == MI355FFT_KERNEL_MAJOR) {
       rc = b.emit_nd(y, out.plus(k * B * oN * 8), fs, rank, B, true, inv_n, err);
       if (rc) return rc;
+      if (d.zero_write.enabled) emit_zero_outside(b, out.plus(k * B * oN * 8), d.zero_write, fs, rank, B);
       continue;
     }
     rc = b.emit_nd(y, y, fs, rank, B, true, inv_n, err);
     if (rc) return rc;
+    if (d.zero_write.enabled) emit_zero_outside(b, y, d.zero_write, fs, rank, B);
     if (d.output.strided) {
       // lane of kernel k: outputOffset + k*kernelStride + b*batchStride (fftconv.js:868-871)
       b.emit_strided(false, out, y, d.output, os, rank, B, fs, ooff, fN, k * kstride);
@@ -1030,6 +1031,7 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       b.emit_strided(false, out, y, ol, os, rank, B, fs, ooff, fN, 0);
     }
   }
+  if (d.zero_write.enabled) b.ir.route += "zero-write ";
   b.ir.route += "fftconv[K=" + std::to_string(K) + "] ";
   return MI355FFT_OK;
 }

@@ -321,11 +321,11 @@ export function resolvePlanOptions(opts) {
   if (zpIn !== undefined && zpIn !== null && typeof zpIn !== "object") throw new Error("zeroPad must be an object with optional read/write stage configs");
   const ioView = { input: normalizeIoView(rank, inLogical, { input: ivIn.input }).input,
                    output: normalizeIoView(rank, outLogical, { output: ivIn.output }).output };
-  const zeroPad = { read: normalizeZeroPad(rank, inLogical, { read: (zpIn || {}).read }).read,
-                    write: normalizeZeroPad(rank, outLogical, { write: (zpIn || {}).write }).write };
-  if (type === "fftconv" && (ioView.input || ioView.output || zeroPad.read || zeroPad.write)) {
-    throw new Error("Unsupported: ioView / zeroPad on fftconv are not built yet (SURVEY.md section 8f rank 2)");
-  }
+  if (type === "fftconv" && (ioView.input || ioView.output)) throw new Error("ioView is not an fftconv option (fftconv.js:308-320)");
+  // fftconv: resolved below against the FFT domain (fftconv.js:353,386)
+  const zeroPad = type === "fftconv" ? { read: null, write: null }
+    : { read: normalizeZeroPad(rank, inLogical, { read: (zpIn || {}).read }).read,
+        write: normalizeZeroPad(rank, outLogical, { write: (zpIn || {}).write }).write };
   const inPlace = !!opts.inPlace;
   const meta = { type, shape, rank, batch, inPlace, ioView, zeroPad };
   const desc = { type: TYPE_CODE[type], shape, batch, inPlace: inPlace ? 1 : 0, direction: 0, normalize: 0 };
@@ -372,6 +372,11 @@ export function resolvePlanOptions(opts) {
         if (outputShape[d] <= 0) throw new Error('fftConv.boundary="linear-valid" requires kernelShape[' + d + "] <= shape[" + d + "]");
       }
     }
+    const fftShape = boundary === "circular" ? shape.slice() : shape.map((n, d) => n + kernelShape[d] - 1);
+    const zpConv = normalizeZeroPad(rank, fftShape, zpIn);
+    if (zpConv.read) desc.zeroRead = zpConv.read;
+    if (zpConv.write) desc.zeroWrite = zpConv.write;
+    meta.zeroPad = zpConv;
     if (inPlace) throw new Error("fftconv inPlace=true is not supported in current implementation");
     const explicitKStride = optPos(fc.outputKernelStrideElements, "fftConv.outputKernelStrideElements") || 0;
     const pol = resolveChannelPolicy(layout, fc.channelPolicy, kernelCount, prod(shape), prod(outputShape));

@@ -63,7 +63,10 @@ test("ioView / zeroPad on r2c and c2r resolve against the real and the packed do
   const c = fft.resolvePlanOptions({ type: "c2r", shape: [16], direction: "inverse", ioView: { input: { shape: [9] }, output: { shape: [24], placement: "center", clearOutside: true } } });
   assert(c.meta.ioView.input === null);
   assert(deepEqual(c.meta.ioView.output, { shape: [24], offset: [-4], clearOutside: true }));
-  assertThrows(() => fft.resolvePlanOptions({ type: "fftconv", shape: [16], fftConv: { kernelCount: 1 }, zeroPad: { read: { start: [1], end: [16] } } }), /Unsupported: ioView \/ zeroPad on fftconv/, "fftconv views");
+  assertThrows(() => fft.resolvePlanOptions({ type: "fftconv", shape: [16], fftConv: { kernelCount: 1 }, ioView: { input: { shape: [4] } } }), /ioView is not an fftconv option/, "fftconv views");
+  // fftconv zeroPad ranges live on the FFT domain: 16 + 5 - 1 = 20 for a linear mode
+  const f = fft.resolvePlanOptions({ type: "fftconv", shape: [16], fftConv: { kernelCount: 1, kernelShape: [5], boundary: "linear-full" }, zeroPad: { write: { start: [2], end: [19] } } });
+  assert(deepEqual(f.desc.zeroWrite, { start: [2], end: [19] }));
 });
 
 test("normalizeScaleFactor matches the reference bit for bit", () => {

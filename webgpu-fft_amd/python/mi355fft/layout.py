@@ -415,10 +415,13 @@ def resolve_plan_options(opts):
                "output": normalize_io_view(rank, out_logical, {"output": iv.get("output")})["output"]}
     if zp is not None and not isinstance(zp, dict):
         raise ValueError("zeroPad must be an object with optional read/write stage configs")
-    zero_pad = {"read": normalize_zero_pad(rank, in_logical, {"read": (zp or {}).get("read")})["read"],
-                "write": normalize_zero_pad(rank, out_logical, {"write": (zp or {}).get("write")})["write"]}
-    if typ == "fftconv" and (io_view["input"] or io_view["output"] or zero_pad["read"] or zero_pad["write"]):
-        raise NotImplementedError("ioView / zeroPad on fftconv are not built yet (SURVEY.md section 8f rank 2)")
+    if typ == "fftconv":
+        if io_view["input"] or io_view["output"]:
+            raise ValueError("ioView is not an fftconv option (fftconv.js:308-320)")
+        zero_pad = {"read": None, "write": None}      # resolved below against the FFT domain (fftconv.js:353,386)
+    else:
+        zero_pad = {"read": normalize_zero_pad(rank, in_logical, {"read": (zp or {}).get("read")})["read"],
+                    "write": normalize_zero_pad(rank, out_logical, {"write": (zp or {}).get("write")})["write"]}
     in_place = bool(opts.get("inPlace", False))
     normalize = opts.get("normalize", "none")
     axes = opts.get("axes")            # createFftPlan({axes}) (plan.js:1335-1339): c2c only; the scale factor keeps prod(shape)
@@ -463,6 +466,8 @@ def resolve_plan_options(opts):
             for d in range(rank):
                 if out_shape[d] <= 0:
                     raise ValueError(f'fftConv.boundary="linear-valid" requires kernelShape[{d}] <= shape[{d}]')
+        fft_shape = list(shape) if boundary == "circular" else [s + k - 1 for s, k in zip(shape, kshape)]
+        out["zero_pad"] = normalize_zero_pad(rank, fft_shape, zp)
         explicit_kstride = _opt_pos(fc.get("outputKernelStrideElements"), "fftConv.outputKernelStrideElements") or 0
         merged_layout, policy_kstride = _resolve_channel_policy(layout, fc.get("channelPolicy"), kernel_count, _prod(shape), _prod(out_shape))
         if explicit_kstride and policy_kstride and explicit_kstride != policy_kstride:
