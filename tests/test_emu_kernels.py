@@ -133,6 +133,31 @@ def test_c2c_axes_subset(oracle, shape, axes):
     check(got, _fft_axes_ref(oracle, x, shape, batch, axes, "forward", 1.0), f"axes={axes} in place", 2e-6)
 
 
+def test_c2c_lane_layout_needs_no_staging(oracle):
+    """rank-1 lane layouts (unit stride along the line, arbitrary offset / batch pitch on both sides): one line-kernel launch,
+    elements between the lanes keep their sentinel"""
+    n, batch = 256, 5
+    x = oracle.random_complex_batch(n, batch, 0x1A9E).reshape(-1)
+    in_off, in_pitch, out_off, out_pitch = 7, 300, 3, 512
+    phys = np.full(2 * (in_off + (batch - 1) * in_pitch + n), 9.0, np.float32)
+    for b in range(batch):
+        phys[2 * (in_off + b * in_pitch):2 * (in_off + b * in_pitch + n)] = x[2 * b * n:2 * (b + 1) * n]
+    out_elems = out_off + (batch - 1) * out_pitch + n
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_elems)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm,
+                              input_layout={"strides": [1], "offset": in_off, "batch_stride": in_pitch},
+                              output_layout={"strides": [1], "offset": out_off, "batch_stride": out_pitch})
+        got, route, launches = emu.run_plan(desc, phys, 2 * out_elems, out_init=sentinel)
+        assert route.startswith("lines[N=256,pitch=300/512]") and launches == 1, route
+        want = sentinel.copy()
+        ref = oracle.c2c_ref_batch(x, [n], batch, direction, norm)
+        for b in range(batch):
+            want[2 * (out_off + b * out_pitch):2 * (out_off + b * out_pitch + n)] = ref[2 * b * n:2 * (b + 1) * n]
+        check(got, want, f"lane layout {direction}", 2e-6)
+        assert np.array_equal(got[:2 * out_off], sentinel[:2 * out_off])
+
+
 def test_c2c_generic_route_matches_lines_route(oracle):
     x = oracle.random_complex_batch(1024, 2, 3).reshape(-1)
     desc = _abi.make_desc("c2c", [1024], 2, "forward", "none")

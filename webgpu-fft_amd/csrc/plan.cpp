@@ -261,6 +261,23 @@ struct Builder {
     return true;
   }
 
+  // Lane layouts (channel-lane presets, whdcn with unit stride along the line): contiguous power-of-two lines that sit at
+  // arbitrary pitches on either side need no gather / scatter pass — the ROW line kernels take the two pitches as they are.
+  bool emit_lines_pitched(PtrRef src, PtrRef dst, int64_t N, int64_t lines, bool inverse, float scale, int64_t in_pitch, int64_t out_pitch) {
+    if (opt.force_generic || !is_pow2(N) || N < 2 || N > 4096 || (opt.xcd_fused == 2 && N == 4096)) return false;
+    const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
+    if (!m) return false;
+    Step& st = push(ST_LINES);
+    st.variant = m->id;
+    st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m);
+    const int64_t tiles = (lines + m->T - 1) / m->T;
+    st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = in_pitch; st.i[4] = 1; st.i[5] = out_pitch;
+    st.f[0] = scale;
+    st.grid = lines_grid(*m, tiles);
+    ir.route += "lines[N=" + std::to_string(N) + ",pitch=" + std::to_string(in_pitch) + "/" + std::to_string(out_pitch) + "] ";
+    return true;
+  }
+
   int emit_axis(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, std::string& err) {
     const int64_t lines = S * outer;
     // work buffers taken inside one axis transform are temporaries: released on every exit
@@ -739,6 +756,18 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   PtrRef in(BUF_INPUT, 0), out(d.in_place ? BUF_INPUT : BUF_OUTPUT, 0);
   b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, ishape, rank, d.batch, 0) * 8 : (uint64_t)in_n * d.batch * 8;
   b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, oshape, rank, d.batch, 0) * 8 : (uint64_t)out_n * d.batch * 8;
+
+  // ---- rank-1 lane layouts: unit stride along the line on both sides -> one launch, no staging ----
+  if (rank == 1 && !vin && !vout && !d.zero_read.enabled && !d.zero_write.enabled && !d.in_place && (d.input.strided || d.output.strided) &&
+      (!d.input.strided || d.input.strides[0] == 1) && (!d.output.strided || d.output.strides[0] == 1)) {
+    const int64_t ip = d.input.strided && d.input.batch_stride_elements > 0 ? d.input.batch_stride_elements : n;
+    const int64_t op = d.output.strided && d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : n;
+    const int64_t ioff = d.input.strided ? d.input.offset_elements : 0, ooff = d.output.strided ? d.output.offset_elements : 0;
+    // the line kernels address a tile with 32-bit element offsets: T lines * pitch must stay below 2^31 elements
+    if (ip >= n && op >= n && ip < ((int64_t)1 << 24) && op < ((int64_t)1 << 24) &&
+        b.emit_lines_pitched(in.plus(ioff * 8), out.plus(ooff * 8), n, d.batch, inverse, scale, ip, op))
+      return MI355FFT_OK;
+  }
 
   // ---- input side: dense logical staging when anything but a plain dense read is asked for ----
   PtrRef src = in;
