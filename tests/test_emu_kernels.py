@@ -42,7 +42,8 @@ def test_c2c_in_place(oracle):
 
 
 @pytest.mark.parametrize("lg,direction", [(13, "forward"), (13, "inverse"), (14, "forward"), (15, "inverse"), (16, "forward"), (17, "forward")])
-def test_c2c_two_pass(oracle, lg, direction):
+def test_c2c_two_pass(oracle, monkeypatch, lg, direction):
+    monkeypatch.setenv("MI355_EMU_MAX_LINE", "4096")      # 2^13 and 2^14 would otherwise run as single-workgroup lines
     n, batch = 1 << lg, 3
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     desc = _abi.make_desc("c2c", [n], batch, direction, "backward")
@@ -55,6 +56,7 @@ def test_c2c_two_pass(oracle, lg, direction):
 def test_c2c_two_pass_hoisted_fourstep_roots(oracle, lg, grid, monkeypatch):
     """grid*T a multiple of N1: pass B computes its four-step roots once per launch (loop-invariant registers)"""
     monkeypatch.setenv("MI355_EMU_MAX_GRID", str(grid))
+    monkeypatch.setenv("MI355_EMU_MAX_LINE", "4096")
     n, batch = 1 << lg, 5
     x = oracle.random_complex_batch(n, batch, 0xB100 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
@@ -131,6 +133,24 @@ def test_c2c_axes_subset(oracle, shape, axes):
     desc = _abi.make_desc("c2c", shape, batch, "forward", "none", in_place=True, axes=axes)
     got, _, _ = emu.run_plan(desc, x, x.size)
     check(got, _fft_axes_ref(oracle, x, shape, batch, axes, "forward", 1.0), f"axes={axes} in place", 2e-6)
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_c2c_single_workgroup_long_lines(oracle, n):
+    """N = 8192 and 16384 still fit one workgroup's LDS (three stages, the last table read from global memory): one launch,
+    one HBM round trip; r2c / c2r of twice the length ride on them"""
+    batch = 3
+    x = oracle.random_complex_batch(n, batch, 0xB16 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith(f"lines[N={n}]") and launches == 1, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction}", 2e-6)
+    xr = oracle.random_real_batch(2 * n, 2, 0xB17 + n).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(xr[b * 2 * n:(b + 1) * 2 * n], 2 * n, "none") for b in range(2)])
+    got, route, _ = emu.run_plan(_abi.make_desc("r2c", [2 * n], 2, "forward", "none"), xr, want.size)
+    assert route.startswith(f"lines[N={n}]"), route
+    check(got, want, f"r2c {2 * n} over lines {n}", 1e-5)
 
 
 def test_c2c_lane_layout_needs_no_staging(oracle):

@@ -133,12 +133,24 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     if fused and lg not in FUSED_LG:
         pytest.skip("no fused instance")
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+    monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
     n, batch = 1 << lg, 3 if lg <= 18 else 2
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
         assert route.startswith("xcd-fused[" if fused else "two-pass[")
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
+
+
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
+    """N = 8192 / 16384: one workgroup per line, last stage table from global memory — one launch, one HBM round trip"""
+    batch = 37
+    x = oracle.random_complex_batch(n, batch, 0xB16 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward"), ("forward", "unitary")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert route.startswith(f"lines[N={n}]") and launches == 1, route
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction} {norm}")
 
 
 @pytest.mark.parametrize("lg,batch", [(18, 150), (19, 75), (21, 37)])

@@ -94,8 +94,12 @@ struct LineCfg {
   static constexpr int TW1_ELEMS = NSTAGES >= 2 ? (R1 - 1) * R0 : 0;
   static constexpr int TW2_ELEMS = NSTAGES == 3 ? (R2 - 1) * R0 * R1 : 0;
   static constexpr int TW_ELEMS = TW1_ELEMS + TW2_ELEMS;
+  // the last table of a three-stage plan has about N entries: beyond 32 KB (N = 8192, 16384) it stays in global memory,
+  // where its reads are L1/L2 hits, so that the line itself still fits the LDS with room for a second workgroup
+  static constexpr bool TW2_IN_LDS = TW2_ELEMS * 8 <= 32 * 1024;
+  static constexpr int TW_LDS_ELEMS = TW1_ELEMS + (TW2_IN_LDS ? TW2_ELEMS : 0);
   static constexpr int LO_ELEMS = TWID == TWID_FOURSTEP_OUT ? 1024 : 0;
-  static constexpr int LDS_BYTES = (DATA_ELEMS + TW_ELEMS + LO_ELEMS) * 8;
+  static constexpr int LDS_BYTES = (DATA_ELEMS + TW_LDS_ELEMS + LO_ELEMS) * 8;
   // every line lives in one wave and only ROW maps are used: exchanges need no workgroup barrier
   static constexpr bool WAVE_LOCAL = !IN_COL && !OUT_COL && TPL <= 64 && (64 % TPL) == 0;
   static_assert(THREADS <= 1024, "workgroup too large");
@@ -212,7 +216,10 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
     for (int q = 0; q < I::R; ++q) w[q] = v[b * I::R + q];
     if constexpr (!I::FIRST) {
 #pragma unroll
-      for (int q = 1; q < I::R; ++q) w[q] = cmul(w[q], tw_lds[I::TW_OFF + (q - 1) * I::NSP + k]);
+      for (int q = 1; q < I::R; ++q) {
+        if constexpr (S == 2 && !C::TW2_IN_LDS) w[q] = cmul(w[q], a.tw[I::TW_OFF + (q - 1) * I::NSP + k]);
+        else w[q] = cmul(w[q], tw_lds[I::TW_OFF + (q - 1) * I::NSP + k]);
+      }
     }
     fft_radix<I::R>(w);
     const int obase_idx = (j / I::NSP) * (I::NSP * I::R) + k;
@@ -245,17 +252,17 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
   MI_SMEM_DECL(smem);
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* tw_lds = lds + C::DATA_ELEMS;
-  cf* lo_lds = tw_lds + C::TW_ELEMS;
+  cf* lo_lds = tw_lds + C::TW_LDS_ELEMS;
   const int t = threadIdx.x;
 
   // stage tables (and the four-step LO table) -> LDS once per workgroup
-  if constexpr (C::TW_ELEMS > 0) {
-    for (int i = t; i < C::TW_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+  if constexpr (C::TW_LDS_ELEMS > 0) {
+    for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
   }
   if constexpr (C::LO_ELEMS > 0) {
     for (int i = t; i < C::LO_ELEMS; i += C::THREADS) lo_lds[i] = a.tw_lo[i & a.fs_lo_mask];
   }
-  if constexpr (C::TW_ELEMS > 0 || C::LO_ELEMS > 0) __syncthreads();
+  if constexpr (C::TW_LDS_ELEMS > 0 || C::LO_ELEMS > 0) __syncthreads();
 
   cf fsw[C::TWID == TWID_FOURSTEP_IN ? C::E : 1];
   // every tile of this workgroup sits at the same position inside its group <=> the tile stride is a

@@ -32,7 +32,8 @@ LineKernelMeta make_meta(int id, int N, int R0, int R1, int R2, int T, bool ic, 
   const int tw2 = nst == 3 ? (R2 - 1) * R0 * R1 : 0;
   m.tw_elems = tw1 + tw2;
   const int lo = twid == 1 ? 1024 : 0;
-  m.lds_bytes = (data + m.tw_elems + lo) * 8;
+  const int tw_lds = tw1 + (tw2 * 8 <= 32 * 1024 ? tw2 : 0);        // LineCfg::TW2_IN_LDS
+  m.lds_bytes = (data + tw_lds + lo) * 8;
   return m;
 }
 }  // namespace
@@ -115,6 +116,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
@@ -264,7 +266,7 @@ struct Builder {
   // Lane layouts (channel-lane presets, whdcn with unit stride along the line): contiguous power-of-two lines that sit at
   // arbitrary pitches on either side need no gather / scatter pass — the ROW line kernels take the two pitches as they are.
   bool emit_lines_pitched(PtrRef src, PtrRef dst, int64_t N, int64_t lines, bool inverse, float scale, int64_t in_pitch, int64_t out_pitch) {
-    if (opt.force_generic || !is_pow2(N) || N < 2 || N > 4096 || (opt.xcd_fused == 2 && N == 4096)) return false;
+    if (opt.force_generic || !is_pow2(N) || N < 2 || N > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;
     const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
     if (!m) return false;
     Step& st = push(ST_LINES);
@@ -288,7 +290,7 @@ struct Builder {
       return MI355FFT_OK;
     }
     const bool p2 = is_pow2(N);
-    if (!opt.force_generic && S == 1 && p2 && N <= 4096 && !(opt.xcd_fused == 2 && N == 4096)) {   // xcd_fused == 2: emulation tests
+    if (!opt.force_generic && S == 1 && p2 && N <= opt.max_line && !(opt.xcd_fused == 2 && N == 4096)) {   // xcd_fused == 2: emulation tests
       const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
       if (m) {
         Step& st = push(ST_LINES);
