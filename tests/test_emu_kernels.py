@@ -438,6 +438,22 @@ def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")
 
 
+@pytest.mark.parametrize("lg,label,cus", [(15, "128x256", 3), (16, "256x256", 2), (17, "256x512", 5)])
+def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
+    """transforms of at most 1 MiB: one workgroup walks a whole transform (both passes, its own workspace slot, no cross-
+    workgroup synchronisation); more transforms than workgroups so that every slot is re-used"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_MAX_GRID", str(cus))        # fewer workgroups than transforms
+    n, batch = 1 << lg, 7
+    x = oracle.random_complex_batch(n, batch, 0x5010 + lg).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith(f"xcd-solo[N={label}]") and launches == 1, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-solo {label} {direction}")
+
+
 @pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (21, "1024x2048")])
 def test_c2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     """the product instances of the fused kernel whose two passes use different tile widths (512x1024: 32-column

@@ -123,7 +123,7 @@ def test_c2c_in_place_and_offsets(fft, dev, oracle):
     out.destroy()
 
 
-FUSED_LG = (18, 19, 20, 21)   # 2^22 stays on the two-launch route   # MI355_XCD_KERNEL_LIST (plan.hpp)
+FUSED_LG = (15, 16, 17, 18, 19, 20, 21)   # 15-17: solo mode; 2^22 stays on the two-launch route   # MI355_XCD_KERNEL_LIST (plan.hpp)
 
 
 @pytest.mark.parametrize("fused", [0, 1])
@@ -138,7 +138,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith("xcd-fused[" if fused else "two-pass[")
+        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused[") if fused else "two-pass["), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
@@ -153,14 +153,14 @@ def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction} {norm}")
 
 
-@pytest.mark.parametrize("lg,batch", [(18, 150), (19, 75), (21, 37)])
+@pytest.mark.parametrize("lg,batch", [(15, 3000), (16, 1500), (17, 700), (18, 150), (19, 75), (21, 37)])
 def test_c2c_fused_many_transforms(fft, dev, oracle, lg, batch):
     """more transforms than groups: every group walks several transforms and alternates its two workspace slots"""
     n = 1 << lg
     x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
-        assert route.startswith("xcd-fused[") and launches == 2
+        assert (route.startswith("xcd-solo[") and launches == 1) if lg <= 17 else (route.startswith("xcd-fused[") and launches == 2), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"fused 2^{lg} x{batch} {direction}")
 
 

@@ -158,7 +158,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.scale = s.f[0];
       a.sticky_error = l.sticky_error_word();
       a.spin_limit = 4000000u;
-      a.split = (unsigned)s.i[8]; a.slots = (unsigned)s.i[11];
+      a.split = (unsigned)s.i[8]; a.slots = (unsigned)s.i[11]; a.solo = (unsigned)s.i[12];
       return xcd_fn(s.variant, a, s.grid);
     }
     case ST_LINES: {

@@ -65,6 +65,8 @@ struct XcdFusedArgs {
   unsigned spin_limit;           // polls before a wait gives up
   unsigned split;                // groups per XCD (1..8): the workgroups of an XCD are divided by rank
   unsigned slots;                // workspace slots per group: 2 (one barrier per transform) or 1 (two barriers, half the footprint)
+  unsigned solo;                 // 1: every workgroup is its own group (transforms of <= 1 MiB): no registration, no cross-
+                                 // workgroup barrier, no co-residency requirement — the grid may be any size, one slot per workgroup
 };
 
 // roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by
@@ -101,6 +103,13 @@ MI_DEV void xcd_arrive(unsigned* counter) {
   MI_WAIT_VMEM();
   __syncthreads();
   if (threadIdx.x == 0) MI_ATOMIC_ADD_U32(counter, 1u);
+}
+// solo mode: producer and consumer are the same workgroup — its stores are complete (vmcnt(0) + workgroup barrier) and its
+// CU's L1 is invalidated (the slot is re-used for every transform, so stale lines of the previous one may sit there)
+MI_DEV void xcd_local_handoff() {
+  MI_WAIT_VMEM();
+  __syncthreads();
+  MI_ACQUIRE_AGENT();
 }
 MI_DEV bool xcd_wait(unsigned* counter, unsigned target, unsigned spin_limit, unsigned* sticky, unsigned* s_flag) {
   if (threadIdx.x == 0) {
@@ -190,7 +199,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
   if constexpr (!TB::SHARED) { for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i]; }
 
-  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  if (f.solo) {
+    if (t == 0) { s_words[0] = blockIdx.x; s_words[1] = 0; s_words[2] = 1; s_words[3] = 1; s_words[4] = blockIdx.x; s_words[5] = gridDim.x; }
+    __syncthreads();
+  } else if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
   const long long N1 = CA::N, N2 = CB::N;
@@ -203,7 +215,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one group barrier per transform.
   // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, loses more than it gains: 150 vs 165
   // GPoints/s at N = 2^20.)
-  const bool two_slots = f.slots != 1u;
+  const bool two_slots = f.slots != 1u && !f.solo;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
@@ -231,8 +243,11 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       }
       __syncthreads();   // LDS is re-used by the next tile
     }
-    xcd_arrive(&f.ctl->bar[gslot][0]);
-    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    if (f.solo) xcd_local_handoff();
+    else {
+      xcd_arrive(&f.ctl->bar[gslot][0]);
+      if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
     // ---- phase B: four-step roots on load, row FFTs, transposed store to the output ----
     ab.in = W; ab.out = f.out + tr * f.out_pitch;
     for (long long i = 0;; ++i) {
@@ -260,7 +275,8 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       }
       __syncthreads();
     }
-    if (!two_slots) {   // everyone has read the slot before phase A of the next transform overwrites it
+    if (f.solo) __syncthreads();   // this workgroup has read its slot before its next phase A overwrites it
+    else if (!two_slots) {   // everyone has read the slot before phase A of the next transform overwrites it
       xcd_arrive(&f.ctl->bar[gslot][1]);
       if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     }

@@ -328,22 +328,37 @@ struct Builder {
       if (xm && (N > 4096 || opt.xcd_fused == 2)) {
         const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
         const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
-        const int64_t split = xcd_split_for((uint64_t)N * 8);
-        const PtrRef wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);   // slots per group x `split` groups per XCC id (16 ids)
-        const PtrRef ctl = alloc_work(16384);
-        std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, N >> 10));
-        for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
-        for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
+        // transforms of at most 1 MiB: every workgroup walks whole transforms alone ("solo": no registration, no cross-
+        // workgroup barrier, so no co-residency requirement and as many workgroups per CU as fit); larger ones are shared by
+        // the groups of an XCD
+        const bool solo = (uint64_t)N * 8 <= ((uint64_t)1 << 20) && opt.xcd_fused != 2;
+        int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+        PtrRef wslots, ctl;
+        if (solo) {
+          const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
+          grid = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)opt.compute_units * per_cu, ((int64_t)256 << 20) / (N * 8)), lines));
+          slots = 1;
+          wslots = alloc_work((uint64_t)grid * N * 8);          // one slot per workgroup, all of them within the Infinity Cache
+          ctl = alloc_work(256);
+        } else {
+          split = xcd_split_for((uint64_t)N * 8);
+          wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);   // slots per group x `split` groups per XCC id (16 ids)
+          ctl = alloc_work(16384);
+        }
+        const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
+        std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
+        for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
+        for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
         const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
-        Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1;
+        if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1; }
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
-        st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023; st.i[9] = N; st.i[10] = N;
-        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = opt.xcd_slots;
+        st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N; st.i[10] = N;
+        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
         st.f[0] = scale;
-        st.grid = (unsigned)opt.compute_units;     // one workgroup per CU (LDS-limited), all co-resident
-        ir.route += "xcd-fused[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        st.grid = (unsigned)grid;      // shared mode: one workgroup per CU (LDS-limited), all co-resident
+        ir.route += std::string(solo ? "xcd-solo[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }

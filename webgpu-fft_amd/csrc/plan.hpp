@@ -40,10 +40,12 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
 
 // XCD-fused four-step kernels (kern_xcd.hpp): X(N1, R0a, R1a, R2a, Ta, N2, R0b, R1b, R2b, Tb); the tile widths are chosen so
 // that both passes use the same workgroup size; each is built forward and inverse.  (64 x 64 exists for the CPU
-// emulation tests.)  N = 2^18, 2^19, 2^20, 2^21 (the c2c half of r2c/c2r N = 2^22).  2^22 = 2048 x 2048 (8-wide tiles on both
+// emulation tests.)  N = 2^15, 2^16, 2^17 (solo mode: one workgroup per transform), 2^18, 2^19, 2^20, 2^21 (the c2c half of
+// r2c/c2r N = 2^22).  2^22 = 2048 x 2048 (8-wide tiles on both
 // passes, 104 B of scratch) was built and measured slower than the two-launch route (104 vs 112 GPoints/s): not instantiated.
 #define MI355_XCD_KERNEL_LIST(X) \
-  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
+  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
+  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
 // r2c and c2r variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; r2c forward, c2r inverse.  2^12 (test instance), 2^18 .. 2^21.
 // (2^22 = 2048 x 2048 with 8-wide tiles on both passes was built and measured slower than the half-length route over the
