@@ -123,6 +123,8 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 8) o.xcd_split = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
+  if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
   return o;
 }
@@ -331,12 +333,12 @@ struct Builder {
         // transforms of at most 1 MiB: every workgroup walks whole transforms alone ("solo": no registration, no cross-
         // workgroup barrier, so no co-residency requirement and as many workgroups per CU as fit); larger ones are shared by
         // the groups of an XCD
-        const bool solo = (uint64_t)N * 8 <= ((uint64_t)1 << 20) && opt.xcd_fused != 2;
+        const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2;
         int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
         PtrRef wslots, ctl;
         if (solo) {
           const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
-          grid = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)opt.compute_units * per_cu, ((int64_t)256 << 20) / (N * 8)), lines));
+          grid = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)opt.compute_units * per_cu, ((int64_t)opt.solo_cap_mb << 20) / (N * 8)), lines));
           slots = 1;
           wslots = alloc_work((uint64_t)grid * N * 8);          // one slot per workgroup, all of them within the Infinity Cache
           ctl = alloc_work(256);

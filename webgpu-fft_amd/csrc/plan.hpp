@@ -103,6 +103,8 @@ struct PlannerOptions {
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
+  int solo_cap_mb = 1024;              // solo mode: all workgroups' workspace slots together (MiB); occupancy matters more than the footprint
+  int solo_max_kb = 1024;              // transforms up to this size run in solo mode
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
