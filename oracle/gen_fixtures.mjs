@@ -303,6 +303,24 @@ import(pathToFileURL(path.join(refRoot, "src/utils/math.js")).href).then((ref) =
     ],
   });
 
+  // ---- DCT / DST (math.js:291-409) — appended last so that the seeds of everything above stay what they were ----
+  {
+    let trigSeed = 0x7a160000;
+    const fns = { dct1: (x, N) => ref.dct1Ref(x, N), dct2: (x, N, d) => ref.dct2Ref(x, N, d), dct3: (x, N, d) => ref.dct3Ref(x, N, d), dct4: (x, N) => ref.dct4Ref(x, N),
+                  dst1: (x, N) => ref.dst1Ref(x, N), dst2: (x, N, d) => ref.dst2Ref(x, N, d), dst3: (x, N, d) => ref.dst3Ref(x, N, d), dst4: (x, N) => ref.dst4Ref(x, N) };
+    for (const type of Object.keys(fns)) {
+      for (const N of [2, 3, 8, 16, 17, 30]) {
+        for (const direction of ["forward", "inverse"]) {
+          const seed = trigSeed++;
+          const input = randomReal(N, mulberry32(seed));
+          const out = fns[type](input, N, direction);
+          const name = `trig_${type}_N${N}_${direction}`;
+          add({ kind: "trig", name, type, N, direction, seed, out_file: writeF32(name + ".out.f32", out) });
+        }
+      }
+    }
+  }
+
   fs.writeFileSync(path.join(outDir, "manifest.json"), JSON.stringify(manifest, null, 1));
   console.log(`wrote ${manifest.cases.length} cases to ${outDir}`);
 }).catch((e) => { console.error(e); process.exit(1); });

@@ -366,3 +366,77 @@ ORACLE_API uint64_t oracle_fnv1a64(const void* data, uint64_t nbytes) {
   for (uint64_t i = 0; i < nbytes; i++) { h ^= p[i]; h *= 0x100000001b3ull; }
   return h;
 }
+
+/* ---- DCT / DST references (math.js:291-409): O(N^2) sums, f64 accumulation, f32 output ----
+ * kind: 0 dct1, 1 dct2 forward (= dct3 inverse), 2 dct2 inverse (= dct3 forward), 3 dct4, 4 dst1, 5 dst2 forward (= dst3
+ * inverse), 6 dst2 inverse (= dst3 forward), 7 dst4 — the typeKind table of runtime/plans/dct_fft.js:48-57 */
+ORACLE_API int oracle_trig1d_ref(const float* in, float* out, int64_t N, int kind) {
+  if (N < 1 || kind < 0 || kind > 7) return -1;
+  if ((kind == 0 || kind == 4) && N < 2) return -1;
+  const double PI = 3.141592653589793;          /* Math.PI */
+  for (int64_t k = 0; k < N; k++) {
+    double sum = 0.0;
+    switch (kind) {
+      case 0:   /* dct1Ref :395-409 */
+        sum = (double)in[0] + ((k % 2 == 0) ? 1.0 : -1.0) * (double)in[N - 1];
+        for (int64_t n = 1; n <= N - 2; n++) sum += 2.0 * (double)in[n] * cos((PI * (double)n * (double)k) / (double)(N - 1));
+        break;
+      case 1:   /* dct2Ref forward :295-303 */
+        for (int64_t n = 0; n < N; n++) sum += (double)in[n] * cos((PI / (double)N) * ((double)n + 0.5) * (double)k);
+        break;
+      case 2:   /* dct2Ref inverse :306-313 (k is the output sample index n) */
+        sum = (double)in[0] * 0.5;
+        for (int64_t q = 1; q < N; q++) sum += (double)in[q] * cos((PI / (double)N) * ((double)k + 0.5) * (double)q);
+        break;
+      case 3:   /* dct4Ref :321-333 */
+        for (int64_t n = 0; n < N; n++) sum += (double)in[n] * cos((PI / (double)N) * ((double)n + 0.5) * ((double)k + 0.5));
+        break;
+      case 4:   /* dst1Ref :335-349 */
+        for (int64_t n = 0; n < N; n++) sum += (double)in[n] * sin((PI * (double)(n + 1) * (double)(k + 1)) / (double)(N + 1));
+        break;
+      case 5:   /* dst2Ref forward :355-363 */
+        for (int64_t n = 0; n < N; n++) sum += (double)in[n] * sin((PI / (double)N) * ((double)n + 0.5) * (double)(k + 1));
+        break;
+      case 6:   /* dst2Ref inverse :366-373 (k is the output sample index n) */
+        sum = ((k % 2 == 0) ? 0.5 : -0.5) * (double)in[N - 1];
+        for (int64_t q = 0; q < N - 1; q++) sum += (double)in[q] * sin((PI / (double)N) * ((double)k + 0.5) * (double)(q + 1));
+        break;
+      default:  /* dst4Ref :381-393 */
+        for (int64_t n = 0; n < N; n++) sum += (double)in[n] * sin((PI / (double)N) * ((double)n + 0.5) * ((double)k + 0.5));
+        break;
+    }
+    out[k] = (float)sum;
+  }
+  return 0;
+}
+
+/* N-D: the 1-D reference along every axis in turn (axis 0 fastest, f32 between axes as the reference's plan stores its
+ * intermediates, dct_fft.js:331-333), then ONE scale by normalizeScaleFactor(prod(shape)) (:882).  This composition is
+ * this build's restatement — the reference has no N-D CPU oracle for these transforms; its suites compare N-D plans to
+ * compositions of 1-D ones. */
+ORACLE_API int oracle_trig_nd_ref(const float* in, float* out, const int64_t* shape, int rank, int64_t batch, int kind, int inverse, int normalize) {
+  const int64_t total = prod_shape(shape, rank);
+  if (total <= 0) return -1;
+  memcpy(out, in, (size_t)(total * batch) * sizeof(float));
+  int64_t S = 1;
+  for (int a = 0; a < rank; a++) {
+    const int64_t N = shape[a];
+    float* line = (float*)malloc((size_t)N * sizeof(float));
+    float* res = (float*)malloc((size_t)N * sizeof(float));
+    if (!line || !res) { free(line); free(res); return -2; }
+    const int64_t lines = batch * (total / N);
+    for (int64_t L = 0; L < lines; L++) {
+      const int64_t o = L / S, inner = L - o * S;
+      float* base = out + o * S * N + inner;
+      for (int64_t n = 0; n < N; n++) line[n] = base[n * S];
+      const int rc = oracle_trig1d_ref(line, res, N, kind);
+      if (rc) { free(line); free(res); return rc; }
+      for (int64_t n = 0; n < N; n++) base[n * S] = res[n];
+    }
+    free(line); free(res);
+    S *= N;
+  }
+  const double scale = oracle_normalize_scale_factor(normalize, inverse, (double)total);
+  if (scale != 1.0) for (int64_t i = 0; i < total * batch; i++) out[i] = (float)((double)out[i] * scale);
+  return 0;
+}

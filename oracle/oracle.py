@@ -50,6 +50,8 @@ def lib():
     L.oracle_fftconv_ref.argtypes = [f32p, f32p, f32p, i64p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                      i64p, ctypes.c_int, i64p]
     L.oracle_fft1d_ref_batch.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    L.oracle_trig1d_ref.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int]
+    L.oracle_trig_nd_ref.argtypes = [f32p, f32p, i64p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.oracle_fnv1a64.restype = ctypes.c_uint64
     L.oracle_fnv1a64.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     _LIB = L
@@ -190,6 +192,29 @@ def fftconv_ref(x, kernel, shape, batch=1, mode="convolution", boundary="circula
     _chk(lib().oracle_fftconv_ref(_f32p(x), _f32p(kernel), _f32p(out), _shape(shape), rank, batch, MODE[mode], BOUNDARY[boundary],
                                   _shape(ks), 1 if use_pow2 else 0, osh), "fftconv_ref")
     return out, list(osh)
+
+
+def trig_kind(typ, direction):
+    """runtime/plans/dct_fft.js:48-57: dct3 = dct2 with the directions exchanged, dst3 likewise"""
+    fwd = direction == "forward"
+    return {"dct1": 0, "dct2": 1 if fwd else 2, "dct3": 2 if fwd else 1, "dct4": 3,
+            "dst1": 4, "dst2": 5 if fwd else 6, "dst3": 6 if fwd else 5, "dst4": 7}[typ]
+
+
+def trig1d_ref(x, n, typ, direction="forward"):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty(n, dtype=np.float32)
+    _chk(lib().oracle_trig1d_ref(_f32p(x), _f32p(out), n, trig_kind(typ, direction)), "trig1d_ref")
+    return out
+
+
+def trig_ref_batch(x, shape, batch, typ, direction="forward", normalize="none"):
+    """DCT / DST of `batch` real arrays of `shape` (axis 0 fastest): the 1-D reference along every axis, one final scale"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    _chk(lib().oracle_trig_nd_ref(_f32p(x), _f32p(out), _shape(shape), len(shape), batch, trig_kind(typ, direction),
+                                  1 if direction == "inverse" else 0, NORMALIZE[normalize]), "trig_nd_ref")
+    return out
 
 
 def fnv1a64(arr):

@@ -109,6 +109,19 @@ def test_dft_path(manifest, oracle):
             _close(oracle.c2r_ref_from_packed(_load(c["in_file"]), c["N"], c["normalize"], use_pow2=False), _load(c["out_file"]))
 
 
+def test_trig_refs(manifest, oracle):
+    """DCT-I..IV / DST-I..IV references against the reference's dct*Ref / dst*Ref (math.js:291-409)"""
+    cases, _ = manifest
+    seen = 0
+    for c in cases.values():
+        if c["kind"] != "trig":
+            continue
+        x = oracle.random_real(c["N"], c["seed"])
+        _close(oracle.trig1d_ref(x, c["N"], c["type"], c["direction"]), _load(c["out_file"]))
+        seen += 1
+    assert seen == 8 * 6 * 2
+
+
 def test_fftconv_ref(manifest, oracle):
     cases, _ = manifest
     seen = 0
