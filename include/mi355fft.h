@@ -38,7 +38,10 @@ typedef struct mi355fft_encoder mi355fft_encoder; /* replaces GPUCommandEncoder:
 typedef struct mi355fft_commands mi355fft_commands; /* replaces GPUCommandBuffer = encoder.finish() */
 
 /* createPlan opts.type (runtime/create_plan.js:12-23); only the hot-path members */
-enum { MI355FFT_C2C = 0, MI355FFT_R2C = 1, MI355FFT_C2R = 2, MI355FFT_FFTCONV = 3 };
+enum { MI355FFT_C2C = 0, MI355FFT_R2C = 1, MI355FFT_C2R = 2, MI355FFT_FFTCONV = 3,
+       /* real-to-real transforms over real f32 buffers (runtime/plans/dct_fft.js; create_plan.js:15) */
+       MI355FFT_DCT1 = 4, MI355FFT_DCT2 = 5, MI355FFT_DCT3 = 6, MI355FFT_DCT4 = 7,
+       MI355FFT_DST1 = 8, MI355FFT_DST2 = 9, MI355FFT_DST3 = 10, MI355FFT_DST4 = 11 };
 /* opts.direction: forward = exp(-i...), inverse = exp(+i...) (kernels/stockham_stage.js:35) */
 enum { MI355FFT_FORWARD = 0, MI355FFT_INVERSE = 1 };
 /* opts.normalize (runtime/common.js:35-40): none -> 1, backward -> 1/N on inverse only, unitary -> 1/sqrt(N) */

@@ -1,0 +1,64 @@
+"""CPU tier: DCT-I..IV / DST-I..IV plans (kern_trig.hpp pre / post passes around the complex FFT routes) under host emulation,
+against the oracle's restatement of the reference's dct*Ref / dst*Ref (math.js:291-409, pinned by tests/golden trig_* fixtures)."""
+import numpy as np
+import pytest
+
+import emu_harness as emu
+from mi355fft import _abi
+from mi355fft.layout import resolve_plan_options
+
+TYPES = ["dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"]
+
+
+def _desc(opts):
+    r = resolve_plan_options(opts)
+    return _abi.make_desc(r["type"], r["shape"], r["batch"], r["direction"], r["normalize"], r["inPlace"], r["input_layout"], r["output_layout"],
+                          None, r["io_view"], r["zero_pad"]), r
+
+
+@pytest.mark.parametrize("typ", TYPES)
+@pytest.mark.parametrize("n", [2, 3, 16, 17, 30, 64])
+def test_trig_1d(oracle, typ, n):
+    batch = 3
+    x = oracle.random_real_batch(n, batch, 0x7A16 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward"), ("forward", "unitary")):
+        desc, _ = _desc({"type": typ, "shape": [n], "batch": batch, "direction": direction, "normalize": norm, "layout": {"interleavedComplex": False}})
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        want = oracle.trig_ref_batch(x, [n], batch, typ, direction, norm)
+        scale = max(1.0, float(np.max(np.abs(want))))
+        assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, (typ, n, direction, route)
+
+
+@pytest.mark.parametrize("typ", ["dct2", "dst3", "dct1", "dst4"])
+def test_trig_nd(oracle, typ):
+    shape, batch = [8, 5, 4], 2
+    n = int(np.prod(shape))
+    x = oracle.random_real_batch(n, batch, 0x7A99).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc, _ = _desc({"type": typ, "shape": shape, "batch": batch, "direction": direction, "normalize": "backward", "layout": {"interleavedComplex": False}})
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        want = oracle.trig_ref_batch(x, shape, batch, typ, direction, "backward")
+        assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), (typ, direction, route)
+
+
+def test_trig_round_trips(oracle):
+    """dct2 -> dct3 and dst2 -> dst3 invert each other up to 2/N; dct4 / dst4 are their own inverses up to 2/N"""
+    n, batch = 32, 2
+    x = oracle.random_real_batch(n, batch, 0x7AAA).reshape(-1)
+    for a, b, factor in (("dct2", "dct3", 2.0 / n), ("dst2", "dst3", 2.0 / n), ("dct4", "dct4", 2.0 / n), ("dst4", "dst4", 2.0 / n),
+                         ("dct1", "dct1", 1.0 / (2 * (n - 1))), ("dst1", "dst1", 2.0 / (n + 1))):
+        d1, _ = _desc({"type": a, "shape": [n], "batch": batch, "layout": {"interleavedComplex": False}})
+        y, _, _ = emu.run_plan(d1, x, x.size)
+        d2, _ = _desc({"type": b, "shape": [n], "batch": batch, "layout": {"interleavedComplex": False}})
+        back, _, _ = emu.run_plan(d2, y, x.size)
+        assert float(np.max(np.abs(back * factor - x))) < 2e-6, (a, b)
+
+
+def test_trig_validation():
+    with pytest.raises(ValueError, match="real buffers"):
+        resolve_plan_options({"type": "dct2", "shape": [8], "layout": {"interleavedComplex": True}})
+    with pytest.raises(ValueError, match="dimensions must be >= 2"):
+        resolve_plan_options({"type": "dst1", "shape": [8, 1], "layout": {"interleavedComplex": False}})
+    with pytest.raises(ValueError, match="inPlace is not supported"):
+        resolve_plan_options({"type": "dct4", "shape": [8], "inPlace": True, "layout": {"interleavedComplex": False}})
+    assert resolve_plan_options({"type": "dct3", "shape": [8], "layout": {"interleavedComplex": False}})["direction"] == "forward"

@@ -595,6 +595,22 @@ def test_accuracy_against_f64(fft, dev, oracle, monkeypatch, lg):
         assert e < 4e-7 and e < 4.0 * ref_err, (route, e, ref_err)
 
 
+@pytest.mark.parametrize("typ", ["dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"])
+def test_dct_dst(fft, dev, oracle, typ):
+    """real-to-real transforms (dct_fft.js) through the pre / FFT / post route: 1-D sizes that hit the line, mixed-radix and
+    Bluestein FFTs underneath, and an N-D array; against the oracle's restatement of math.js:291-409"""
+    for shape, batch in (([16], 5), ([17], 3), ([1000], 4), ([4096], 2), ([12, 10, 3], 2)):
+        n = int(np.prod(shape))
+        x = oracle.random_real_batch(n, batch, 0x7A16 + n).reshape(-1)
+        for direction, norm in (("forward", "none"), ("inverse", "backward")):
+            got, (route, _) = run_plan(fft, dev, {"type": typ, "shape": shape, "batch": batch, "direction": direction, "normalize": norm,
+                                                   "layout": {"interleavedComplex": False}}, x, x.size)
+            want = oracle.trig_ref_batch(x, shape, batch, typ, direction, norm)
+            scale = max(1.0, float(np.max(np.abs(want))))
+            # the reference's own tolerance for these plans is 2e-3 (complete.suite.js:3932); f32 FFTs of length 2N do far better
+            assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-4 * scale, (typ, shape, direction, route)
+
+
 def test_torch_fft_cross_check(fft, dev, oracle):
     """independent f32 FFT (torch.fft on the same GPU) agrees to f32 rounding — not the parity oracle"""
     torch = pytest.importorskip("torch")

@@ -55,7 +55,8 @@ def test_option_validation_messages():
         with pytest.raises(ValueError, match=re.escape(frag)):
             layout.resolve_plan_options(opts)
     with pytest.raises(NotImplementedError):
-        layout.resolve_plan_options({"type": "dct2", "shape": [8], "direction": "forward"})
+        layout.resolve_plan_options({"type": "conv2d", "shape": [8]})
+    assert layout.resolve_plan_options({"type": "dct2", "shape": [8], "direction": "forward"})["type"] == "dct2"   # real buffers by default
 
 
 def test_whdcn_resolution():

@@ -13,6 +13,7 @@
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
 #include "kern_mixed.hpp"
+#include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
 #include "plan.hpp"
 
@@ -170,6 +171,14 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.scale = s.f[0];
       const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
       return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);
+    }
+    case ST_TRIG_PRE:
+    case ST_TRIG_POST: {
+      TrigArgs a{};
+      a.x = (const float*)ptr[0]; a.z = (cf*)ptr[1]; a.y = (float*)ptr[2];
+      a.lines = s.i[0]; a.N = s.i[1]; a.L = s.i[2]; a.S = s.i[3]; a.kind = (int)s.i[4]; a.scale = s.f[0];
+      if (s.kind == ST_TRIG_PRE) l.launch(trig_pre_kernel, s.grid, 256u, 0u, a); else l.launch(trig_post_kernel, s.grid, 256u, 0u, a);
+      return true;
     }
     case ST_LINES_MIXED: {
       MixedArgs a{};

@@ -1,0 +1,86 @@
+// kern_trig.hpp — DCT-I..IV / DST-I..IV as a complex FFT of length L with a pre- and a post-pass per axis (SURVEY.md 8f rank 4;
+// replaces src/runtime/plans/dct_fft.js for the real, f32 case).  Completeness route: three launches + one FFT per axis.
+//
+// kind (the typeKind table of dct_fft.js:48-57; dct3 / dst3 are dct2 / dst2 with the directions exchanged), theta = pi/(2N):
+//   0 dct1      L = 2(N-1)  z = even extension of x                         X[k] = Re Z[k]
+//   1 dct2 fwd  L = 2N      z[n] = x[n] (n < N), 0 beyond                   X[k] = Re(e^{-i theta k} Z[k])
+//   2 dct2 inv  L = 2N      z[k] = c_k X[k] e^{+i theta k}, c_0 = 1/2       x[n] = Re IFFT(z)[n]   (unnormalised)
+//   3 dct4      L = 2N      z[n] = x[n] e^{-i theta n}                      X[k] = Re(e^{-i theta (k+1/2)} Z[k])
+//   4 dst1      L = 2(N+1)  z = odd extension of x (z[0] = z[N+1] = 0)      X[k] = -Im Z[k+1] / 2
+//   5 dst2 fwd  L = 2N      as kind 1                                       X[k] = -Im(e^{-i theta (k+1)} Z[k+1])
+//   6 dst2 inv  L = 2N      z[m] = c_m X[m-1] e^{+i theta m}, m = 1..N, c_N = 1/2     x[n] = Im IFFT(z)[n]
+//   7 dst4      L = 2N      as kind 3                                       X[k] = -Im(e^{-i theta (k+1/2)} Z[k])
+// (each identity follows from writing the cosine / sine of the definitions in math.js:291-409 as the real / imaginary
+// part of a complex exponential and splitting the exponent into the FFT kernel and per-index phase factors)
+//
+// Lines of an N-D real array as in StageArgs: line G -> (o = G / S, inner = G % S), element p at o*S*N + inner + p*S.
+// The complex work array holds the lines back to back: [line][L].
+#pragma once
+#include "platform.hpp"
+#include "radix.hpp"
+
+namespace mi355 {
+
+struct TrigArgs {
+  const float* x;     // pre: real input array; post: unused
+  cf* z;              // complex work lines
+  float* y;           // post: real output array
+  long long lines, N, L, S;
+  int kind;
+  float scale;        // post only
+};
+
+MI_DEV cf trig_phase(double turns_half) {   // e^{i pi t}
+  double s, c;
+#ifdef MI355_HOST_EMU
+  s = std::sin(3.14159265358979323846 * turns_half); c = std::cos(3.14159265358979323846 * turns_half);
+#else
+  sincospi(turns_half, &s, &c);
+#endif
+  cf r; r.x = (float)c; r.y = (float)s;
+  return r;
+}
+
+static __global__ void __launch_bounds__(256) trig_pre_kernel(const TrigArgs a) {
+  const long long total = a.lines * a.L;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long G = g / a.L, m = g - G * a.L;
+    const long long o = G / a.S, base = o * a.S * a.N + (G - o * a.S);
+    const auto X = [&](long long p) { return a.x[base + p * a.S]; };
+    const double inv2n = 1.0 / (2.0 * (double)a.N);
+    cf z; z.x = 0.0f; z.y = 0.0f;
+    switch (a.kind) {
+      case 0: z.x = X(m < a.N ? m : a.L - m); break;
+      case 1: case 5: if (m < a.N) z.x = X(m); break;
+      case 2: if (m < a.N) { const cf w = trig_phase((double)m * inv2n); const float c = (m == 0 ? 0.5f : 1.0f) * X(m); z.x = c * w.x; z.y = c * w.y; } break;
+      case 3: case 7: if (m < a.N) { const cf w = trig_phase(-(double)m * inv2n); const float v = X(m); z.x = v * w.x; z.y = v * w.y; } break;
+      case 4: if (m >= 1 && m <= a.N) z.x = X(m - 1); else if (m > a.N + 1) z.x = -X(a.L - m - 1); break;
+      case 6: if (m >= 1 && m <= a.N) { const cf w = trig_phase((double)m * inv2n); const float c = (m == a.N ? 0.5f : 1.0f) * X(m - 1); z.x = c * w.x; z.y = c * w.y; } break;
+    }
+    a.z[g] = z;
+  }
+}
+
+static __global__ void __launch_bounds__(256) trig_post_kernel(const TrigArgs a) {
+  const long long total = a.lines * a.N;
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long G = g / a.N, k = g - G * a.N;
+    const long long o = G / a.S, base = o * a.S * a.N + (G - o * a.S);
+    const cf* Z = a.z + G * a.L;
+    const double inv2n = 1.0 / (2.0 * (double)a.N);
+    float r = 0.0f;
+    switch (a.kind) {
+      case 0: r = Z[k].x; break;
+      case 1: { const cf w = trig_phase(-(double)k * inv2n); const cf v = Z[k]; r = v.x * w.x - v.y * w.y; } break;
+      case 2: r = Z[k].x; break;
+      case 3: { const cf w = trig_phase(-((double)k + 0.5) * inv2n); const cf v = Z[k]; r = v.x * w.x - v.y * w.y; } break;
+      case 4: r = -0.5f * Z[k + 1].y; break;
+      case 5: { const cf w = trig_phase(-(double)(k + 1) * inv2n); const cf v = Z[k + 1]; r = -(v.x * w.y + v.y * w.x); } break;
+      case 6: r = Z[k].y; break;
+      case 7: { const cf w = trig_phase(-((double)k + 0.5) * inv2n); const cf v = Z[k]; r = -(v.x * w.y + v.y * w.x); } break;
+    }
+    a.y[base + k * a.S] = r * a.scale;
+  }
+}
+
+}  // namespace mi355

@@ -957,6 +957,57 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
 
 // y_k = IFFT( FFT(x) .* (conj?)FFT(h_k) ) / Nfft, cropped per boundary, written per output layout / lanes
 // (runtime/plans/fftconv.js:308-709, exec :1415-1712; reference semantics: src/utils/math.js:469-603)
+// DCT-I..IV / DST-I..IV over real buffers (dct_fft.js): per axis a pre-pass into complex lines of length L, the complex FFT
+// of those lines, a post-pass back into the real array (kern_trig.hpp); one scale by normalizeScaleFactor(prod(shape)) folded
+// into the last post-pass (dct_fft.js:882).  Layout strides, ioView and zeroPad ride the same side staging as r2c / c2r.
+int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
+  if (d.direction != MI355FFT_FORWARD && d.direction != MI355FFT_INVERSE) { err = "direction must be one of \"forward\", \"inverse\""; return MI355FFT_ERR_INVALID; }
+  if (d.in_place) { err = "DCT/DST inPlace is not supported in current implementation"; return MI355FFT_ERR_INVALID; }
+  const int rank = d.rank;
+  for (int i = 0; i < rank; ++i) if (d.shape[i] < 2) { err = "All DCT/DST dimensions must be >= 2"; return MI355FFT_ERR_INVALID; }
+  if (int rv = validate_views(d, err)) return rv;
+  const bool fwd = d.direction == MI355FFT_FORWARD;
+  int kind;
+  switch (d.type) {                                     // dct_fft.js:48-57
+    case MI355FFT_DCT1: kind = 0; break;
+    case MI355FFT_DCT2: kind = fwd ? 1 : 2; break;
+    case MI355FFT_DCT3: kind = fwd ? 2 : 1; break;
+    case MI355FFT_DCT4: kind = 3; break;
+    case MI355FFT_DST1: kind = 4; break;
+    case MI355FFT_DST2: kind = fwd ? 5 : 6; break;
+    case MI355FFT_DST3: kind = fwd ? 6 : 5; break;
+    default: kind = 7; break;
+  }
+  const int64_t n = prodv(d.shape, rank);
+  const float scale = (float)scale_factor(d.normalize, !fwd, (double)n);
+  const PtrRef user_out(BUF_OUTPUT, 0);
+  PtrRef cur = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
+  const PtrRef dst = side_output_target(d, b, user_out, d.shape, true, b.ir.out_bytes);
+  int64_t S = 1;
+  for (int a = 0; a < rank; ++a) {
+    const int64_t N = d.shape[a], lines = d.batch * (n / N);
+    const int64_t L = kind == 0 ? 2 * (N - 1) : (kind == 4 ? 2 * (N + 1) : 2 * N);
+    const uint64_t mark = b.work_top;
+    const PtrRef z = b.alloc_work((uint64_t)lines * L * 8);
+    Step& pre = b.push(ST_TRIG_PRE);
+    pre.p[0] = cur; pre.p[1] = z; pre.p[2] = dst;
+    pre.i[0] = lines; pre.i[1] = N; pre.i[2] = L; pre.i[3] = S; pre.i[4] = kind;
+    pre.grid = b.generic_grid(lines * L);
+    const int rc = b.emit_axis(z, z, L, 1, lines, kind == 2 || kind == 6, 1.0f, err);
+    if (rc) return rc;
+    Step& post = b.push(ST_TRIG_POST);
+    post.p[0] = cur; post.p[1] = z; post.p[2] = dst;
+    post.i[0] = lines; post.i[1] = N; post.i[2] = L; post.i[3] = S; post.i[4] = kind;
+    post.f[0] = a == rank - 1 ? scale : 1.0f;
+    post.grid = b.generic_grid(lines * N);
+    b.work_top = mark;         // the complex lines are a per-axis temporary
+    cur = dst;
+    S *= N;
+  }
+  b.ir.route += "trig[kind=" + std::to_string(kind) + "] ";
+  return finish_side_output(d, b, user_out, dst, d.shape, true, err);
+}
+
 int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   if (d.io_input.enabled || d.io_output.enabled) { err = "ioView is not an fftconv option"; return MI355FFT_ERR_INVALID; }
   if (d.in_place) { err = "fftconv inPlace=true is not supported in current implementation"; return MI355FFT_ERR_INVALID; }
@@ -1096,6 +1147,8 @@ int build_plan(const mi355fft_plan_desc& desc, const PlannerOptions& opt, PlanIR
     case MI355FFT_C2C: rc = build_c2c(desc, b, err); break;
     case MI355FFT_R2C: rc = build_r2c(desc, b, err); break;
     case MI355FFT_C2R: rc = build_c2r(desc, b, err); break;
+    case MI355FFT_DCT1: case MI355FFT_DCT2: case MI355FFT_DCT3: case MI355FFT_DCT4:
+    case MI355FFT_DST1: case MI355FFT_DST2: case MI355FFT_DST3: case MI355FFT_DST4: rc = build_trig(desc, b, err); break;
     case MI355FFT_FFTCONV: rc = build_fftconv(desc, b, err); break;
     default: err = "type must be one of \"c2c\", \"r2c\", \"c2r\", \"fftconv\" (other createPlan types are outside the MI355X hot path)"; rc = MI355FFT_ERR_UNSUPPORTED;
   }

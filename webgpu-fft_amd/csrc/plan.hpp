@@ -73,7 +73,7 @@ struct PtrRef {
 
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
-  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED, ST_TRIG_PRE, ST_TRIG_POST
 };
 
 // One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).

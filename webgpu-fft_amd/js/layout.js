@@ -15,7 +15,8 @@ const CONFLICTING_LAYOUT_KEYS = ["whdcn", "strides", "inputStrides", "outputStri
 const HOT_PATH_TYPES = ["c2c", "r2c", "c2r", "fftconv"];
 const ALL_TYPES = ["c2c", "r2c", "c2r", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4", "fftconv", "conv2d"];
 
-export const TYPE_CODE = { c2c: 0, r2c: 1, c2r: 2, fftconv: 3 };
+export const TYPE_CODE = { c2c: 0, r2c: 1, c2r: 2, fftconv: 3, dct1: 4, dct2: 5, dct3: 6, dct4: 7, dst1: 8, dst2: 9, dst3: 10, dst4: 11 };
+const TRIG_TYPES = ["dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"];   // real-to-real, real f32 buffers (dct_fft.js)
 export const DIRECTION_CODE = { forward: 0, inverse: 1 };
 export const NORMALIZE_CODE = { none: 0, backward: 1, unitary: 2 };
 export const CONV_MODE_CODE = { convolution: 0, correlation: 1 };
@@ -295,7 +296,8 @@ export function resolvePlanOptions(opts) {
   if (!isPlainObject(opts)) throw new Error("createPlan expects an options object");
   const type = opts.type;
   assertOneOf(type, ALL_TYPES, "type");
-  if (!HOT_PATH_TYPES.includes(type)) {
+  const trig = TRIG_TYPES.includes(type);
+  if (!HOT_PATH_TYPES.includes(type) && !trig) {
     throw new Error('Unsupported: type "' + type + '" is outside the MI355X hot path (c2c/r2c/c2r/fftconv); see DESIGN.md "out of scope"');
   }
   const shapeIn = opts.shape;
@@ -307,8 +309,12 @@ export function resolvePlanOptions(opts) {
   const rank = shape.length;
   const batch = dflt(opts.batch, 1);
   if (!Number.isInteger(batch) || batch <= 0) throw new Error("batch must be positive int; got " + batch);
-  const layout = dflt(opts.layout, { interleavedComplex: true });
-  if (!isPlainObject(layout) || layout.interleavedComplex !== true) throw new Error(type + " requires layout.interleavedComplex=true");
+  const layout = dflt(opts.layout, { interleavedComplex: !trig });
+  if (trig) {
+    if (!isPlainObject(layout) || layout.interleavedComplex !== false) throw new Error("DCT/DST uses real buffers; set layout.interleavedComplex=false");
+    if (shape.some((n) => n < 2)) throw new Error("All DCT/DST dimensions must be >= 2; got shape=" + JSON.stringify(shape));
+    if (opts.inPlace) throw new Error("DCT/DST inPlace is not supported in current implementation");
+  } else if (!isPlainObject(layout) || layout.interleavedComplex !== true) throw new Error(type + " requires layout.interleavedComplex=true");
   const precision = dflt(opts.precision, "f32");
   assertOneOf(precision, ["f32", "f16-storage"], "precision");
   if (precision !== "f32") throw new Error('Unsupported: precision "f16-storage" is outside the MI355X hot path (f32 only)');
@@ -396,7 +402,7 @@ export function resolvePlanOptions(opts) {
     return { desc, meta };
   }
 
-  const direction = opts.direction;
+  const direction = opts.direction === undefined && trig ? "forward" : opts.direction;   // dct_fft.js:70: DCT/DST default to forward
   assertOneOf(direction, ["forward", "inverse"], "direction");
   const normalize = dflt(opts.normalize, "none");
   assertOneOf(normalize, ["none", "backward", "unitary"], "normalize");

@@ -43,7 +43,9 @@ test("option validation messages", () => {
     [{ type: "r2c", shape: [8], direction: "inverse" }, /r2c supports direction:"forward" only/],
     [{ type: "c2r", shape: [8], direction: "forward" }, /c2r supports direction:"inverse" only/],
     [{ type: "fftconv", shape: [8], fftConv: { kernelShape: [9] } }, /must be <= shape/],
-    [{ type: "dct2", shape: [8], direction: "forward" }, /outside the MI355X hot path/],
+    [{ type: "dct2", shape: [8], direction: "forward", layout: { interleavedComplex: true } }, /DCT\/DST uses real buffers; set layout.interleavedComplex=false/],
+    [{ type: "dst1", shape: [8, 1], layout: { interleavedComplex: false } }, /All DCT\/DST dimensions must be >= 2/],
+    [{ type: "conv2d", shape: [8] }, /outside the MI355X hot path/],
     [{ type: "bogus", shape: [8] }, /type must be one of/],
   ];
   for (const [opts, re] of bad) assertThrows(() => fft.resolvePlanOptions(opts), re, JSON.stringify(opts));
@@ -67,6 +69,12 @@ test("ioView / zeroPad on r2c and c2r resolve against the real and the packed do
   // fftconv zeroPad ranges live on the FFT domain: 16 + 5 - 1 = 20 for a linear mode
   const f = fft.resolvePlanOptions({ type: "fftconv", shape: [16], fftConv: { kernelCount: 1, kernelShape: [5], boundary: "linear-full" }, zeroPad: { write: { start: [2], end: [19] } } });
   assert(deepEqual(f.desc.zeroWrite, { start: [2], end: [19] }));
+});
+
+test("DCT / DST options resolve (dct_fft.js:66-101): real buffers, direction defaults to forward", () => {
+  const r = fft.resolvePlanOptions({ type: "dct3", shape: [16, 4], batch: 2, normalize: "unitary", layout: { interleavedComplex: false } });
+  assert(r.desc.type === 6 && r.desc.direction === 0 && r.desc.normalize === 2 && r.meta.direction === "forward");
+  assert(fft.resolvePlanOptions({ type: "dst4", shape: [8], direction: "inverse", layout: { interleavedComplex: false } }).desc.type === 11);
 });
 
 test("normalizeScaleFactor matches the reference bit for bit", () => {

@@ -10,7 +10,8 @@ MAX_RANK = 8
 C2C, R2C, C2R, FFTCONV = 0, 1, 2, 3
 FORWARD, INVERSE = 0, 1
 NORM = {"none": 0, "backward": 1, "unitary": 2}
-TYPE = {"c2c": C2C, "r2c": R2C, "c2r": C2R, "fftconv": FFTCONV}
+TYPE = {"c2c": C2C, "r2c": R2C, "c2r": C2R, "fftconv": FFTCONV,
+        "dct1": 4, "dct2": 5, "dct3": 6, "dct4": 7, "dst1": 8, "dst2": 9, "dst3": 10, "dst4": 11}
 DIRECTION = {"forward": FORWARD, "inverse": INVERSE}
 CONV_MODE = {"convolution": 0, "correlation": 1}
 CONV_BOUNDARY = {"circular": 0, "linear-full": 1, "linear-same": 2, "linear-valid": 3}

@@ -17,6 +17,7 @@ FFTCONV_OUTPUT_LAYOUTS = ("kernel-major", "batch-major")
 CONFLICTING_LAYOUT_KEYS = ("whdcn", "strides", "inputStrides", "outputStrides", "offsetElements", "inputOffsetElements",
                            "outputOffsetElements", "batchStrideElements", "inputBatchStrideElements", "outputBatchStrideElements")
 HOT_PATH_TYPES = ("c2c", "r2c", "c2r", "fftconv")
+TRIG_TYPES = ("dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4")   # real-to-real, real f32 buffers (dct_fft.js)
 ALL_TYPES = ("c2c", "r2c", "c2r", "dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4", "fftconv", "conv2d")
 
 
@@ -386,7 +387,7 @@ def resolve_plan_options(opts):
         raise ValueError("createPlan expects an options object")
     typ = opts.get("type")
     _assert_one_of(typ, ALL_TYPES, "type")
-    if typ not in HOT_PATH_TYPES:
+    if typ not in HOT_PATH_TYPES and typ not in TRIG_TYPES:
         raise NotImplementedError(f'type "{typ}" is outside the MI355X hot path (c2c/r2c/c2r/fftconv); see DESIGN.md "out of scope"')
     shape = opts.get("shape")
     if not isinstance(shape, (list, tuple)) or len(shape) < 1:
@@ -398,8 +399,16 @@ def resolve_plan_options(opts):
     batch = opts.get("batch", 1)
     if not _is_int(batch) or batch <= 0:
         raise ValueError(f"batch must be positive int; got {batch}")
-    layout = opts.get("layout", {"interleavedComplex": True})
-    if not isinstance(layout, dict) or layout.get("interleavedComplex") is not True:
+    trig = typ in TRIG_TYPES
+    layout = opts.get("layout", {"interleavedComplex": not trig})
+    if trig:
+        if not isinstance(layout, dict) or layout.get("interleavedComplex") is not False:
+            raise ValueError("DCT/DST uses real buffers; set layout.interleavedComplex=false")
+        if any(s < 2 for s in shape):
+            raise ValueError(f"All DCT/DST dimensions must be >= 2; got shape={shape!r}")
+        if opts.get("inPlace", False):
+            raise ValueError("DCT/DST inPlace is not supported in current implementation")
+    elif not isinstance(layout, dict) or layout.get("interleavedComplex") is not True:
         raise ValueError(f"{typ} requires layout.interleavedComplex=true")
     precision = opts.get("precision", "f32")
     _assert_one_of(precision, ("f32", "f16-storage"), "precision")
@@ -481,7 +490,7 @@ def resolve_plan_options(opts):
             raise ValueError("fftconv inPlace=true is not supported in current implementation")
         return out
 
-    direction = opts.get("direction")
+    direction = opts.get("direction", "forward" if trig else None)     # dct_fft.js:70: DCT/DST default to forward
     _assert_one_of(direction, ("forward", "inverse"), "direction")
     _assert_one_of(normalize, ("none", "backward", "unitary"), "normalize")
     if typ == "r2c" and direction != "forward":
