@@ -342,6 +342,23 @@ def test_c2r_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     check(got, x, f"xcd-c2r {label}", 1e-5)
 
 
+@pytest.mark.parametrize("lg,label", [(15, "128x256"), (16, "256x256"), (17, "256x512")])
+def test_real_four_step_solo_sizes(oracle, monkeypatch, lg, label):
+    """real / Hermitian four-step with one workgroup per transform (real lines of at most 512 KB): r2c against the oracle, c2r back"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "3")
+    monkeypatch.setenv("MI355_EMU_MAX_GRID", "3")
+    n, batch = 1 << lg, 7
+    x = oracle.random_real_batch(n, batch, 0xD400 + lg).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
+    got, route, launches = emu.run_plan(_abi.make_desc("r2c", [n], batch, "forward", "none"), x, want.size)
+    assert route.startswith(f"xcd-r2c-solo[N={label}]") and launches == 1, route
+    check(got, want, f"xcd-r2c-solo {label}", 1e-5)
+    back, route, launches = emu.run_plan(_abi.make_desc("c2r", [n], batch, "inverse", "backward"), want, n * batch)
+    assert route.startswith(f"xcd-c2r-solo[N={label}]") and launches == 1, route
+    check(back, x, f"xcd-c2r-solo {label}", 1e-5)
+
+
 def test_r2c_rejects_inverse_and_c2r_rejects_forward():
     for typ, direction, frag in (("r2c", "inverse", "forward"), ("c2r", "forward", "inverse")):
         desc = _abi.make_desc(typ, [16], 1, direction, "none")

@@ -36,7 +36,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
   for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
   if constexpr (!TB::SHARED) { for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i]; }
 
-  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  if (f.solo) {   // one workgroup per transform (kern_xcd.hpp): no registration, no cross-workgroup barrier
+    if (t == 0) { s_words[0] = blockIdx.x; s_words[1] = 0; s_words[2] = 1; s_words[3] = 1; s_words[4] = blockIdx.x; s_words[5] = gridDim.x; }
+    __syncthreads();
+  } else if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
   constexpr int N1 = CA::N, N2 = CB::N, ROWS = N1 / 2 + 1;
@@ -46,7 +49,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
   aa.in_S = N2 / 2; aa.in_outer_stride = f.N / 2; aa.out_S = N2 / 2; aa.out_outer_stride = f.N / 2; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = (ROWS + CB::T - 1) / CB::T; ab.num_lines = ROWS;
   ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
-  const bool two_slots = f.slots != 1u;
+  const bool two_slots = f.slots != 1u && !f.solo;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)wsize;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
@@ -85,8 +88,11 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
       }
       __syncthreads();   // LDS is re-used by the next tile
     }
-    xcd_arrive(&f.ctl->bar[gslot][0]);
-    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    if (f.solo) xcd_local_handoff();
+    else {
+      xcd_arrive(&f.ctl->bar[gslot][0]);
+      if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
     // ---- phase B: rows 0..N1/2, four-step roots, row FFT, transposed store with the Hermitian mirror ----
     ab.in = W;
     cf* const po = f.out + tr * f.out_pitch;
@@ -147,7 +153,8 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
       }
       __syncthreads();
     }
-    if (!two_slots) {
+    if (f.solo) __syncthreads();
+    else if (!two_slots) {
       xcd_arrive(&f.ctl->bar[gslot][1]);
       if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     }
@@ -187,7 +194,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
   for (int i = t; i < CA::TW_ELEMS; i += CA::THREADS) tw_a[i] = f.tw_a[i];
   if constexpr (!TB::SHARED) { for (int i = t; i < CB::TW_ELEMS; i += CA::THREADS) tw_b[i] = f.tw_b[i]; }
 
-  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  if (f.solo) {   // one workgroup per transform (kern_xcd.hpp): no registration, no cross-workgroup barrier
+    if (t == 0) { s_words[0] = blockIdx.x; s_words[1] = 0; s_words[2] = 1; s_words[3] = 1; s_words[4] = blockIdx.x; s_words[5] = gridDim.x; }
+    __syncthreads();
+  } else if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
   constexpr int N1 = CA::N, N2 = CB::N, COLS = N2 / 2 + 1, WP = N2 / 2 + 16;   // live columns, row pitch of W
@@ -197,7 +207,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
   aa.out_S = WP; aa.out_outer_stride = wsize; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = (N1 / 2) / CB::T; ab.num_lines = N1 / 2;
   ab.out_S = N1 / 2; ab.out_outer_stride = f.N / 2; ab.scale = f.scale; ab.fs_group = N1;
-  const bool two_slots = f.slots != 1u;
+  const bool two_slots = f.slots != 1u && !f.solo;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)wsize;
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
@@ -237,8 +247,11 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
       }
       __syncthreads();
     }
-    xcd_arrive(&f.ctl->bar[gslot][0]);
-    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    if (f.solo) xcd_local_handoff();
+    else {
+      xcd_arrive(&f.ctl->bar[gslot][0]);
+      if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
     // ---- phase B ----
     ab.out = f.out + tr * f.out_pitch;
     for (long long i = 0;; ++i) {
@@ -296,7 +309,8 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
       }
       __syncthreads();
     }
-    if (!two_slots) {
+    if (f.solo) __syncthreads();
+    else if (!two_slots) {
       xcd_arrive(&f.ctl->bar[gslot][1]);
       if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     }

@@ -244,24 +244,36 @@ struct Builder {
     const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
     const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
-    const int64_t split = xcd_split_for((uint64_t)wsize * 8);
-    const PtrRef wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * wsize * 8);
-    const PtrRef ctl = alloc_work(16384);
+    // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
+    const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / 2 && opt.xcd_fused != 2;
+    int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+    PtrRef wslots, ctl;
+    if (solo) {
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
+      grid = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)opt.compute_units * per_cu, ((int64_t)opt.solo_cap_mb << 20) / (wsize * 8)), lines));
+      slots = 1;
+      wslots = alloc_work((uint64_t)grid * wsize * 8);
+      ctl = alloc_work(256);
+    } else {
+      split = xcd_split_for((uint64_t)wsize * 8);
+      wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * wsize * 8);
+      ctl = alloc_work(16384);
+    }
     const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
     std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
     for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
     const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
-    Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1;
+    if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 4096; z.grid = 1; }
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
     st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
     st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1;
     st.i[9] = c2r ? N / 2 + 1 : N / 2; st.i[10] = c2r ? N / 2 : N / 2 + 1;        // pitches in complex elements
-    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = opt.xcd_slots;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
     st.f[0] = scale;
-    st.grid = (unsigned)opt.compute_units;
-    ir.route += std::string(c2r ? "xcd-c2r[N=" : "xcd-r2c[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    st.grid = (unsigned)grid;
+    ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
     return true;
   }
 

@@ -47,15 +47,17 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
   X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
-// r2c and c2r variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; r2c forward, c2r inverse.  2^12 (test instance), 2^18 .. 2^21.
+// r2c and c2r variants (kern_xcd_real.hpp), same parameters: a real line of N1*N2 points; r2c forward, c2r inverse.  2^12 (test instance), 2^15 .. 2^17 (solo mode), 2^18 .. 2^21.
 // (2^22 = 2048 x 2048 with 8-wide tiles on both passes was built and measured slower than the half-length route over the
 // fused c2c kernel — 153-163 vs 183 G real points/s — and is not instantiated.)
 #define MI355_XCD_R2C_KERNEL_LIST(X) \
-  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
+  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
+  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
 // c2r: 2^21 (1024 x 2048, 396 B of scratch per lane) measured 140 vs 215 G real points/s for the half-length route: not instantiated
 #define MI355_XCD_C2R_KERNEL_LIST(X) \
-  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
+  X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
+  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16)
 struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; };   // real: 0 c2c, 1 r2c, 2 c2r
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
