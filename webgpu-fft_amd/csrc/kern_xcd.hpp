@@ -43,7 +43,7 @@ constexpr bool XCD_NT = MI355_XCD_NT != 0;   // nontemporal x loads / output sto
 struct XcdCtl {                  // zeroed by a memset step before every launch
   unsigned reg_total;
   unsigned reg_xcd[16];
-  unsigned bar[128][16];         // one 64-byte line per group (XCC id x split): [0] A->B barrier, [1] B->A barrier (one-slot mode)
+  unsigned bar[512][16];         // one 64-byte line per group (XCC id x split): [0] A->B barrier, [1] B->A barrier (one-slot mode)
 };
 
 struct XcdFusedArgs {
@@ -63,7 +63,7 @@ struct XcdFusedArgs {
   int fs_shift;
   unsigned fs_lo_mask;
   unsigned spin_limit;           // polls before a wait gives up
-  unsigned split;                // groups per XCD (1..8): the workgroups of an XCD are divided by rank
+  unsigned split;                // groups per XCD (1..32): the workgroups of an XCD are divided by rank
   unsigned slots;                // workspace slots per group: 2 (one barrier per transform) or 1 (two barriers, half the footprint)
   unsigned solo;                 // 1: every workgroup is its own group (transforms of <= 1 MiB): no registration, no cross-
                                  // workgroup barrier, no co-residency requirement — the grid may be any size, one slot per workgroup
