@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "webgpu-fft_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
+ND_SHAPE = []   # set by an N-D probe workload
 WORKLOADS = {
     # name: (type, N, batch per GPU, algorithmic bytes per point, description)
     "c2c_2p20_b4096": ("c2c", 1 << 20, 4096, 16, "1D c2c N=2^20 batch=4096 f32 forward, out-of-place (BASELINE config 3, north-star metric)"),
@@ -157,21 +158,29 @@ def main():
         torch.cuda.set_device(local_rank)
     group = Group("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; barrier + scalar reductions only
 
-    if args.workload not in WORKLOADS:   # probes: c2c_2pL_bB / r2c_2pL_bB (never the headline line)
+    if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r)_(2p|n)(\d+)_b(\d+)", args.workload)
-        if not m:
+        nd = re.fullmatch(r"c2c_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
+        if nd:
+            ND_SHAPE[:] = [int(v) for v in nd.group(1).split("x")]
+            tot = 1
+            for v in ND_SHAPE:
+                tot *= v
+            WORKLOADS[args.workload] = ("c2c", tot, int(nd.group(2)), 16, f"{len(ND_SHAPE)}-D c2c {nd.group(1)} batch={nd.group(2)} (probe; NOT a BASELINE config)")
+        elif m:
+            nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
+            WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) == "c2c" else 8,
+                                        f"1D {m.group(1)} N={nn} batch={m.group(4)} (probe; NOT a BASELINE config)")
+        else:
             raise SystemExit(f"unknown workload {args.workload}")
-        nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
-        WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) == "c2c" else 8,
-                                    f"1D {m.group(1)} N={nn} batch={m.group(4)} (probe; NOT a BASELINE config)")
     typ, n, batch, bytes_per_point, desc = WORKLOADS[args.workload]
     dev = mi355fft.Device(local_rank, use_graph=False if args.no_graph else "auto")
     info = dev.info()
     if typ == "c2c":
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n
-        opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+        opts = {"type": "c2c", "shape": list(ND_SHAPE) if ND_SHAPE else [n], "batch": batch, "direction": "forward", "normalize": "none"}
     elif typ == "r2c":
         in_bytes, out_bytes = n * batch * 4, (n // 2 + 1) * batch * 8
         in_row_floats = n

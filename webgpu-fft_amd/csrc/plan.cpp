@@ -427,7 +427,9 @@ struct Builder {
     int ns = (int)radices.size();
     const std::vector<int> lds_radices = factorize_radices(N, 8);
     // (short lines that the stage route finishes in three passes with a radix-16/32 first stage measured faster there: 640, 768)
-    const bool stages_win = S == 1 && N < 1024 && radices.size() == 3 && radices[0] >= 16 && opt.mixed_lines != 2;
+    // (strided axes need T >= 8 adjacent lines per workgroup for coalesced accesses: N <= 512; longer ones keep the stage route —
+    // measured 27 GPoints/s for the 4096-point axis of a 4096x4096 array with T = 1)
+    const bool stages_win = ((S == 1 && N < 1024 && radices.size() == 3 && radices[0] >= 16) || (S > 1 && N > 512)) && opt.mixed_lines != 2;
     if (opt.mixed_lines && !opt.force_generic && !stages_win && lds_radices.size() >= 2 && lds_radices.size() <= 12 && N <= 4096) {
       const std::vector<int>& radices = lds_radices;
       ns = (int)radices.size();
