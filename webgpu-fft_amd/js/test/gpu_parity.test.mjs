@@ -260,7 +260,32 @@ test("error behaviour: destroyed plan, missing output, in-place aliasing, offset
   assertThrows(() => q.exec(dev.createCommandEncoder(), { input: a, output: b }), /inPlace=true requires output omitted or equal to input/);
   assert(typeof q.getWorkspaceSizeBytes() === "number" && q.getPipelineCacheSnapshot().schema === "webgpufft.pipeline-cache");
   q.destroy(); a.destroy(); b.destroy();
-  assertThrows(() => fft.createPlan(dev, { type: "dct2", shape: [16], direction: "forward" }), /Unsupported/);
+  assertThrows(() => fft.createPlan(dev, { type: "conv2d", shape: [16] }), /Unsupported/);
+});
+
+test("dct2 / dst2 over real buffers (complete.suite.js:3885-3932 shape): N=16 against the defining sums", async () => {
+  const dev = await ensureDevice();
+  const N = 16;
+  const x = orc.randomReal(N, orc.mulberry32(901));
+  const xb = dev.createBuffer({ size: N * 4, usage: 0 });
+  dev.queue.writeBuffer(xb, 0, x);
+  for (const type of ["dct2", "dst2"]) {
+    const want = new Float32Array(N);
+    for (let k = 0; k < N; ++k) {
+      let sum = 0;
+      for (let n = 0; n < N; ++n) sum += x[n] * (type === "dct2" ? Math.cos((Math.PI / N) * (n + 0.5) * k) : Math.sin((Math.PI / N) * (n + 0.5) * (k + 1)));
+      want[k] = sum;
+    }
+    const yb = dev.createBuffer({ size: N * 4, usage: 0 });
+    const p = fft.createPlan(dev, { type, shape: [N], direction: "forward", normalize: "none", layout: { interleavedComplex: false }, precision: "f32" });
+    const enc = dev.createCommandEncoder();
+    p.exec(enc, { input: xb, output: yb });
+    dev.queue.submit([enc.finish()]);
+    const got = await fft.downloadComplex(dev, yb, N / 2);          // N real floats
+    check(got, want, 2e-3, 2e-3, type + " N=16");
+    p.destroy(); yb.destroy();
+  }
+  xb.destroy();
 });
 
 run();
