@@ -471,6 +471,25 @@ def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-solo {label} {direction}")
 
 
+@pytest.mark.parametrize("shape,label,extra", [([256, 256], "xcd-2d-solo[256x256]", []), ([512, 512], "xcd-2d[512x512]", []), ([256, 256, 3], "xcd-2d-solo[256x256]", [3])])
+def test_c2c_2d_fused(oracle, monkeypatch, shape, label, extra):
+    """square power-of-two planes: axes 0 and 1 in one fused launch (columns, barrier, rows in natural order); a third axis follows"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "4")
+    monkeypatch.setenv("MI355_EMU_XCDS", "2")
+    batch = 3 if len(shape) == 2 else 2
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0x2D00 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", shape, batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith(label), route
+        check(got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{label} {direction}", 3e-6)
+    desc = _abi.make_desc("c2c", shape, batch, "forward", "unitary", in_place=True)
+    got, route, _ = emu.run_plan(desc, x, x.size)
+    check(got, oracle.c2c_ref_batch(x, shape, batch, "forward", "unitary"), f"{label} in place", 3e-6)
+
+
 @pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (21, "1024x2048")])
 def test_c2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     """the product instances of the fused kernel whose two passes use different tile widths (512x1024: 32-column

@@ -142,6 +142,19 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("shape,batch", [([256, 256], 40), ([512, 512], 20), ([1024, 1024], 5), ([256, 256, 4], 3)])
+def test_c2c_2d_planes(fft, dev, oracle, monkeypatch, shape, batch, fused):
+    """square power-of-two planes: both axes in one fused launch (columns, barrier, rows in natural order) vs one launch per axis"""
+    monkeypatch.setenv("MI355FFT_XCD_2D", str(fused))
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0x2D00 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": shape, "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert route.startswith("xcd-2d") == bool(fused), route
+        check(oracle, got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} ({route.strip()})")
+
+
 @pytest.mark.parametrize("n", [8192, 16384])
 def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
     """N = 8192 / 16384: one workgroup per line, last stage table from global memory — one launch, one HBM round trip"""

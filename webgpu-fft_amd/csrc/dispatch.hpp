@@ -81,7 +81,8 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
 // per lane in a unit with eleven siblings; r2c 1024x2048: 88 B against 264 B).
 #define MI_XCD_PLUS2(...) +2
 #define MI_XCD_PLUS1(...) +1
-constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1);
+constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1)
+                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2);
 #undef MI_XCD_PLUS2
 #undef MI_XCD_PLUS1
 
@@ -96,7 +97,7 @@ enum { MI_XCD_COUNTER_BASE = __COUNTER__ + 1 };
     if constexpr (ONLY < 0 || ONLY == ME) {                                                       \
       if (id == ME) {                                                                             \
         using CA = LineCfg<N1_, A0_, A1_, A2_, TA_, true, true, SWAP, false, 0>;                   \
-        using CB = LineCfg<N2_, B0_, B1_, B2_, TB_, false, true, false, SWAP, 0>;                  \
+        using CB = LineCfg<N2_, B0_, B1_, B2_, TB_, false, MI_XCD_B_OUT_COL, false, SWAP, 0>;      \
         using F = XcdFusedCfg<CA, CB>;                                                            \
         l.launch_concurrent(KERNEL<CA, CB>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a); \
         return true;                                                                              \
@@ -106,6 +107,7 @@ enum { MI_XCD_COUNTER_BASE = __COUNTER__ + 1 };
 #define MI_XCD_PARAMS(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) \
   constexpr int N1_ = N1, A0_ = A0, A1_ = A1, A2_ = A2, TA_ = TA, N2_ = N2, B0_ = B0, B1_ = B1, B2_ = B2, TB_ = TB;
 template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, unsigned grid, L& l) {
+#define MI_XCD_B_OUT_COL true
 #define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_fused_kernel, false) MI_XCD_CASE(fft_xcd_fused_kernel, true) }
   MI355_XCD_KERNEL_LIST(X)
 #undef X
@@ -115,6 +117,12 @@ template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, 
 #define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_c2r_kernel, false) }
   MI355_XCD_C2R_KERNEL_LIST(X)
 #undef X
+#undef MI_XCD_B_OUT_COL
+#define MI_XCD_B_OUT_COL false      /* 2-D: the second pass is a ROW kernel, natural order out */
+#define X(...) { MI_XCD_PARAMS(__VA_ARGS__) MI_XCD_CASE(fft_xcd_fused_kernel, false) MI_XCD_CASE(fft_xcd_fused_kernel, true) }
+  MI355_XCD_2D_KERNEL_LIST(X)
+#undef X
+#undef MI_XCD_B_OUT_COL
   static_assert(__COUNTER__ - MI_XCD_COUNTER_BASE == XCD_INSTANCE_COUNT, "instance ids out of step with the lists");
   return false;
 }

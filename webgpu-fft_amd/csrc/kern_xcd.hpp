@@ -187,7 +187,10 @@ template <class CA, class CB> struct XcdTables {
 template <class CA, class CB>
 __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFusedArgs f) {
   static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
-  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL && CB::OUT_COL, "PASS_A then PASS_B");
+  static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL, "PASS_A, then PASS_B (four-step) or ROW (two-dimensional)");
+  // TWO_D: a 2-D transform of an [N1][N2] array is the same two passes without the four-step roots and with the rows written
+  // back in natural order (the second pass is a ROW configuration)
+  constexpr bool TWO_D = !CB::OUT_COL;
   MI_SMEM_DECL(smem);
   cf* lds = reinterpret_cast<cf*>(smem);
   constexpr int DATA = CA::DATA_ELEMS > CB::DATA_ELEMS ? CA::DATA_ELEMS : CB::DATA_ELEMS;
@@ -210,7 +213,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   aa.tw = f.tw_a; aa.num_tiles = N2 / CA::T; aa.num_lines = N2;
   aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = N1 / CB::T; ab.num_lines = N1;
-  ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = N1; ab.out_outer_stride = f.N; ab.scale = f.scale; ab.fs_group = N1;
+  ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = TWO_D ? 1 : N1; ab.out_outer_stride = TWO_D ? N2 : f.N; ab.scale = f.scale; ab.fs_group = N1;
   // Two workspace slots per group, alternated per transform: the barrier between A(k+1) and B(k+1) also orders "everyone
   // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one group barrier per transform.
   // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, loses more than it gains: 150 vs 165
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       if (tile >= ab.num_tiles) continue;
       cf v[CB::E];
       stage_read<CB, 0, MI355_XCD_W_NT_LD != 0>(v, ab, tile, t, lds);
-      {
+      if constexpr (!TWO_D) {
         int line, u; thread_map<CB, 0>(t, line, u);
         fourstep_apply_chain<CB>(v, f, (unsigned)(tile * CB::T + line), u);
       }

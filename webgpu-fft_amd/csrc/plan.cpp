@@ -87,7 +87,7 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
 #define XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, INV, REAL)                                       \
   {                                                                                                       \
     const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, INV, false, 0);                \
-    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, true, false, INV, 0);               \
+    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, (REAL) != 3, false, INV, 0);        \
     XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, INV, ma.threads, 0, REAL};          \
     const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
     const bool shared = N1 == N2 && A0 == B0 && A1 == B1 && A2 == B2;                                     \
@@ -104,6 +104,11 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
 #undef X
 #define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB) XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, 2)
     MI355_XCD_C2R_KERNEL_LIST(X)
+#undef X
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, false, 3)                                              \
+  XCD_META(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB, true, 3)
+    MI355_XCD_2D_KERNEL_LIST(X)
 #undef X
 #undef XCD_META
     return r;
@@ -123,6 +128,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 32) o.xcd_split = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_2D")) o.xcd_2d = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
@@ -231,6 +237,44 @@ struct Builder {
     int64_t split = 8;
     while (split > 1 && (uint64_t)(8 * opt.xcd_slots * split) * slot_bytes > ((uint64_t)320 << 20)) split >>= 1;   // (r2c slots are N/2 + N2 points: a little over a power of two)
     return split;
+  }
+
+  // 2-D c2c planes [N1][N0] (axis 0 = N0 fastest) through the fused kernel's TWO_D instances; false if none applies
+  bool emit_xcd_2d(PtrRef src, PtrRef dst, int64_t N0, int64_t N1, int64_t planes, bool inverse, float scale) {
+    if (opt.force_generic || opt.xcd_fused != 1 || opt.only_pass || !opt.xcd_2d) return false;
+    const XcdKernelMeta* xm = nullptr;
+    for (const auto& m : xcd_kernel_registry()) if (m.real == 3 && m.N1 == N1 && m.N2 == N0 && m.inverse == inverse) xm = &m;
+    if (!xm) return false;
+    const int64_t N = N0 * N1;
+    const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+    const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, false, false, false, 0);
+    const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10);
+    int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+    PtrRef wslots, ctl;
+    if (solo) {
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
+      grid = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((int64_t)opt.compute_units * per_cu, ((int64_t)opt.solo_cap_mb << 20) / (N * 8)), planes));
+      slots = 1;
+      wslots = alloc_work((uint64_t)grid * N * 8);
+      ctl = alloc_work(256);
+    } else {
+      split = xcd_split_for((uint64_t)N * 8);
+      wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);
+      ctl = alloc_work(40960);
+      if (xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;
+    }
+    std::vector<float2h> one(1, float2h{1, 0});
+    const PtrRef ta = line_tables(ma), tb = line_tables(mb), tone = add_table(one);
+    if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
+    Step& st = push(ST_XCD_FUSED);
+    st.variant = xm->id;
+    st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+    st.i[0] = planes; st.i[1] = N; st.i[2] = 0; st.i[3] = 0; st.i[9] = N; st.i[10] = N;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tone.off; st.i[7] = tone.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
+    st.f[0] = scale;
+    st.grid = (unsigned)grid;
+    ir.route += std::string(solo ? "xcd-2d-solo[" : "xcd-2d[") + std::to_string(N0) + "x" + std::to_string(N1) + "] ";
+    return true;
   }
 
   // XCD-fused r2c of `lines` dense real lines of length N into packed spectra of N/2+1 bins; false if no instance applies
@@ -591,7 +635,13 @@ struct Builder {
     int last_axis = -1;
     const auto wanted = [&](int a) { return axes_mask == 0 || ((axes_mask >> a) & 1u); };
     for (int a = first_axis; a < rank; ++a) if (shape[a] > 1 && wanted(a)) last_axis = a;
-    for (int a = first_axis; a < rank; ++a) {
+    int start = first_axis;
+    // axes 0 and 1 of square power-of-two planes in ONE persistent launch (kern_xcd.hpp TWO_D): columns, barrier, rows
+    if (first_axis == 0 && rank >= 2 && wanted(0) && wanted(1) &&
+        emit_xcd_2d(cur, dst, shape[0], shape[1], batch * (total / (shape[0] * shape[1])), inverse, last_axis == 1 ? scale : 1.0f)) {
+      cur = dst; any = true; S = shape[0] * shape[1]; start = 2;
+    }
+    for (int a = start; a < rank; ++a) {
       const int64_t N = shape[a];
       if (N > 1 && wanted(a)) {
         const int64_t outer = batch * (total / (S * N));

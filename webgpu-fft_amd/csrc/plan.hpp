@@ -59,7 +59,11 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
   X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16)
-struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; };   // real: 0 c2c, 1 r2c, 2 c2r
+// 2-D c2c of an [N1][N0] array (axis 0 = N0 fastest): X(N1, radices, Ta, N0, radices, Tb) — columns of N1 (pass A), barrier,
+// rows of N0 with a ROW kernel (natural order out, no four-step roots); forward and inverse
+#define MI355_XCD_2D_KERNEL_LIST(X) \
+  X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16)
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
@@ -104,6 +108,7 @@ struct PlannerOptions {
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
+  int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int solo_cap_mb = 1024;              // solo mode: all workgroups' workspace slots together (MiB); occupancy matters more than the footprint
   int solo_max_kb = 1024;              // transforms up to this size run in solo mode
