@@ -471,7 +471,8 @@ def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-solo {label} {direction}")
 
 
-@pytest.mark.parametrize("shape,label,extra", [([256, 256], "xcd-2d-solo[256x256]", []), ([512, 512], "xcd-2d[512x512]", []), ([256, 256, 3], "xcd-2d-solo[256x256]", [3])])
+@pytest.mark.parametrize("shape,label,extra", [([256, 256], "xcd-2d-solo[256x256]", []), ([512, 512], "xcd-2d[512x512]", []), ([256, 256, 3], "xcd-2d-solo[256x256]", [3]),
+                                               ([512, 256], "xcd-2d-solo[512x256]", []), ([1024, 512], "xcd-2d[1024x512]", []), ([512, 1024], "xcd-2d[512x1024]", [])])
 def test_c2c_2d_fused(oracle, monkeypatch, shape, label, extra):
     """square power-of-two planes: axes 0 and 1 in one fused launch (columns, barrier, rows in natural order); a third axis follows"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")

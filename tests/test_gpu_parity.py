@@ -143,9 +143,10 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
 
 
 @pytest.mark.parametrize("fused", [0, 1])
-@pytest.mark.parametrize("shape,batch", [([256, 256], 40), ([512, 512], 20), ([1024, 1024], 5), ([256, 256, 4], 3)])
+@pytest.mark.parametrize("shape,batch", [([256, 256], 40), ([512, 512], 20), ([1024, 1024], 5), ([256, 256, 4], 3),
+                                         ([512, 256], 20), ([256, 512], 20), ([512, 1024], 6), ([1024, 512], 6)])
 def test_c2c_2d_planes(fft, dev, oracle, monkeypatch, shape, batch, fused):
-    """square power-of-two planes: both axes in one fused launch (columns, barrier, rows in natural order) vs one launch per axis"""
+    """power-of-two planes with sides of 256, 512 or 1024: both axes in one fused launch (columns, barrier, rows in natural order) vs one launch per axis"""
     monkeypatch.setenv("MI355FFT_XCD_2D", str(fused))
     n = int(np.prod(shape))
     x = oracle.random_complex_batch(n, batch, 0x2D00 + n).reshape(-1)

@@ -60,9 +60,12 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
   X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16)
 // 2-D c2c of an [N1][N0] array (axis 0 = N0 fastest): X(N1, radices, Ta, N0, radices, Tb) — columns of N1 (pass A), barrier,
-// rows of N0 with a ROW kernel (natural order out, no four-step roots); forward and inverse
+// rows of N0 with a ROW kernel (natural order out, no four-step roots); forward and inverse.  Tile widths chosen so that both
+// passes use the same workgroup size (256 threads for the 256/512 planes, 512 with a 1024 side)
 #define MI355_XCD_2D_KERNEL_LIST(X) \
-  X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16)
+  X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) \
+  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 256, 16, 16, 1, 16) \
+  X(1024, 32, 32, 1, 16, 512, 32, 16, 1, 32) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16)
 struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
