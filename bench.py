@@ -161,13 +161,14 @@ def main():
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r)_(2p|n)(\d+)_b(\d+)", args.workload)
-        nd = re.fullmatch(r"c2c_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
+        nd = re.fullmatch(r"(c2c|r2c)_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
         if nd:
-            ND_SHAPE[:] = [int(v) for v in nd.group(1).split("x")]
+            ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
             tot = 1
             for v in ND_SHAPE:
                 tot *= v
-            WORKLOADS[args.workload] = ("c2c", tot, int(nd.group(2)), 16, f"{len(ND_SHAPE)}-D c2c {nd.group(1)} batch={nd.group(2)} (probe; NOT a BASELINE config)")
+            WORKLOADS[args.workload] = (nd.group(1), tot, int(nd.group(3)), 16 if nd.group(1) == "c2c" else 8,
+                                        f"{len(ND_SHAPE)}-D {nd.group(1)} {nd.group(2)} batch={nd.group(3)} (probe; NOT a BASELINE config)")
         elif m:
             nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
             WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) == "c2c" else 8,
@@ -182,9 +183,11 @@ def main():
         in_row_floats = 2 * n
         opts = {"type": "c2c", "shape": list(ND_SHAPE) if ND_SHAPE else [n], "batch": batch, "direction": "forward", "normalize": "none"}
     elif typ == "r2c":
-        in_bytes, out_bytes = n * batch * 4, (n // 2 + 1) * batch * 8
+        shp = list(ND_SHAPE) if ND_SHAPE else [n]
+        packed = (shp[0] // 2 + 1) * (n // shp[0])
+        in_bytes, out_bytes = n * batch * 4, packed * batch * 8
         in_row_floats = n
-        opts = {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"}
+        opts = {"type": "r2c", "shape": shp, "batch": batch, "direction": "forward", "normalize": "none"}
     else:   # c2r probe: random packed spectra (not Hermitian-consistent in bins 0 and N/2; irrelevant for timing)
         in_bytes, out_bytes = (n // 2 + 1) * batch * 8, n * batch * 4
         in_row_floats = 2 * (n // 2 + 1)

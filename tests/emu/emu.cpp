@@ -107,10 +107,12 @@ int emu_check_registry(char* msg, size_t msg_bytes) {
 #define LINE_ROW(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, false, false, false, false, 0) CHECK(N, R0, R1, R2, T, false, false, true, true, 0)
 #define LINE_PASS_A(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, true, true, false, false, 0) CHECK(N, R0, R1, R2, T, true, true, true, false, 0) CHECK(N, R0, R1, R2, T, true, true, true, true, 0)
 #define LINE_PASS_B(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, false, true, false, false, 2) CHECK(N, R0, R1, R2, T, false, true, false, true, 2)
+#define LINE_COL_RAGGED(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, true, true, false, false, 3) CHECK(N, R0, R1, R2, T, true, true, true, true, 3)
 #include "line_kernels.def"
 #undef LINE_ROW
 #undef LINE_PASS_A
 #undef LINE_PASS_B
+#undef LINE_COL_RAGGED
 #undef CHECK
   if (cur != (int)reg.size()) { std::snprintf(msg, msg_bytes, "registry size %d != %zu", cur, reg.size()); ++bad; }
   return bad;

@@ -153,6 +153,39 @@ def test_c2c_single_workgroup_long_lines(oracle, n):
     check(got, want, f"r2c {2 * n} over lines {n}", 1e-5)
 
 
+@pytest.mark.parametrize("shape", [[40, 128], [17, 64], [24, 64, 3]])
+def test_c2c_ragged_column_groups(oracle, shape):
+    """a power-of-two axis whose stride is not a multiple of the 16-line tile: per-group tiles with a ragged last one"""
+    batch = 2
+    n = int(np.prod(shape))
+    x = oracle.random_complex_batch(n, batch, 0x4A66 + n).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", shape, batch, direction, norm)
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert f"columns-ragged[N={shape[1]},S={shape[0]}]" in route, route
+        check(got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"ragged {shape} {direction}", 3e-6)
+
+
+def test_r2c_c2r_2d_packed_columns(oracle):
+    """2-D r2c: the second axis runs over the 33 packed bins of a 64-point first axis (ragged column groups); c2r back"""
+    shape, batch = [64, 128], 2
+    n, p = 64 * 128, 33
+    x = oracle.random_real_batch(n, batch, 0x4A77).reshape(-1)
+    want = []
+    for b in range(batch):
+        cplx = np.zeros(2 * n, np.float32)
+        cplx[0::2] = x[b * n:(b + 1) * n]
+        full = oracle.fftnd_ref(cplx, shape, "forward", "none").reshape(shape[1], shape[0], 2)
+        want.append(full[:, :p, :].reshape(-1))
+    want = np.concatenate(want)
+    got, route, _ = emu.run_plan(_abi.make_desc("r2c", shape, batch, "forward", "none"), x, want.size)
+    assert "columns-ragged[N=128,S=33]" in route, route
+    check(got, want, "r2c 2-D ragged columns", 3e-6)
+    back, route, _ = emu.run_plan(_abi.make_desc("c2r", shape, batch, "inverse", "backward"), want, n * batch)
+    assert "columns-ragged[N=128,S=33]" in route, route
+    check(back, x, "c2r 2-D ragged columns", 3e-6)
+
+
 def test_c2c_lane_layout_needs_no_staging(oracle):
     """rank-1 lane layouts (unit stride along the line, arbitrary offset / batch pitch on both sides): one line-kernel launch,
     elements between the lanes keep their sentinel"""

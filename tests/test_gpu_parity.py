@@ -156,6 +156,24 @@ def test_c2c_2d_planes(fft, dev, oracle, monkeypatch, shape, batch, fused):
         check(oracle, got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} ({route.strip()})")
 
 
+def test_r2c_c2r_2d_real_images(fft, dev, oracle):
+    """2-D r2c / c2r of 512x512 and 256x1024 real planes: the second axis walks the packed bins (stride 257 / 129: ragged column
+    groups); against the full complex oracle and back to the signal"""
+    for shape, batch in (([512, 512], 6), ([256, 1024], 4), ([64, 64, 8], 3)):
+        n, p = int(np.prod(shape)), shape[0] // 2 + 1
+        x = oracle.random_real_batch(n, batch, 0x4A88 + n).reshape(-1)
+        cplx = np.zeros(2 * n * batch, np.float32)
+        cplx[0::2] = x
+        full = oracle.c2c_ref_batch(cplx, shape, batch, "forward", "none").reshape(batch, n // shape[0], shape[0], 2)
+        want = np.ascontiguousarray(full[:, :, :p, :]).reshape(-1)
+        got, (route, _) = run_plan(fft, dev, {"type": "r2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "none"}, x, want.size)
+        assert "columns-ragged[" in route, route
+        check(oracle, got, want, f"r2c {shape} ({route.strip()})", 8e-4, 8e-4)
+        back, (route, _) = run_plan(fft, dev, {"type": "c2r", "shape": shape, "batch": batch, "direction": "inverse", "normalize": "backward"}, want, n * batch)
+        assert "columns-ragged[" in route, route
+        check(oracle, back, x, f"c2r {shape} ({route.strip()})", 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize("n", [8192, 16384])
 def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
     """N = 8192 / 16384: one workgroup per line, last stage table from global memory — one launch, one HBM round trip"""

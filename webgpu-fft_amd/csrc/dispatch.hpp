@@ -45,10 +45,14 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
 #define LINE_PASS_B(N, R0, R1, R2, T)                                \
   MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, false, 2) \
   MI_LINE_CASE(FAM_PASS_B, N, R0, R1, R2, T, false, true, false, true, 2)
+#define LINE_COL_RAGGED(N, R0, R1, R2, T)                             \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 3) \
+  MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, true, 3)
 #include "line_kernels.def"
 #undef LINE_ROW
 #undef LINE_PASS_A
 #undef LINE_PASS_B
+#undef LINE_COL_RAGGED
 #undef MI_LINE_CASE
   (void)cur; (void)a; (void)grid; (void)l;
   return false;

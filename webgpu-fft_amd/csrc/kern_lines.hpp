@@ -50,7 +50,10 @@ template <bool NT = false> MI_DEV void st_stream(cf* p, cf v) {
 //   TWID_FOURSTEP_IN   multiplied into the first stage's inputs from per-thread registers that are computed
 //                      once per kernel launch when every tile of a workgroup has the same position inside its
 //                      group (grid * T is a multiple of the group), else once per tile
-enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1, TWID_FOURSTEP_IN = 2 };
+enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1, TWID_FOURSTEP_IN = 2,
+             // no roots; COL sides whose group width S is NOT a multiple of T (e.g. the 513 packed bins of a 2-D r2c): tiles are
+             // numbered per group (fs_group = tiles per group), the last tile of a group is ragged
+             COL_RAGGED = 3 };
 
 struct LineArgs {
   const cf* in;
@@ -67,7 +70,7 @@ struct LineArgs {
   float scale;
   int fs_shift;
   unsigned fs_lo_mask;
-  long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group)
+  long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group); COL_RAGGED: tiles per group
 };
 
 template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_, bool SWAP_IN_, bool SWAP_OUT_, int TWID_>
@@ -164,11 +167,19 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
   int line, u; thread_map<C, S>(t, line, u);
   if constexpr (I::FIRST) {
     const long long G0 = tile * C::T;
-    const cf* p = a.in + tile_base<C::IN_COL>(G0, a.in_S, a.in_outer_stride);
+    const cf* p;
+    long long live_lines;
+    if constexpr (C::TWID == COL_RAGGED) {
+      const long long o = tile / a.fs_group, j0 = (tile - o * a.fs_group) * C::T;   // group, first line of the tile inside it
+      p = a.in + o * a.in_outer_stride + j0;
+      live_lines = a.in_S - j0;
+    } else {
+      p = a.in + tile_base<C::IN_COL>(G0, a.in_S, a.in_outer_stride);
+      // padding lines of the last tile re-read its last live line (loads stay in bounds, stores are masked)
+      live_lines = a.num_lines - G0;
+    }
     const unsigned ls = C::IN_COL ? 1u : (unsigned)a.in_outer_stride;
     const unsigned es = C::IN_COL ? (unsigned)a.in_S : 1u;
-    // padding lines of the last tile re-read its last live line (loads stay in bounds, stores are masked)
-    const long long live_lines = a.num_lines - G0;
     const int lclamp = (long long)line < live_lines ? line : (int)live_lines - 1;
     const unsigned voff = (unsigned)lclamp * ls + (unsigned)u * es;
 #pragma unroll
@@ -201,10 +212,16 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
   bool live = true;
   if constexpr (TO_GLOBAL) {
     const long long G0 = tile * C::T;
-    po = a.out + tile_base<C::OUT_COL>(G0, a.out_S, a.out_outer_stride);
+    if constexpr (C::TWID == COL_RAGGED) {
+      const long long o = tile / a.fs_group, j0 = (tile - o * a.fs_group) * C::T;
+      po = a.out + o * a.out_outer_stride + j0;
+      live = (long long)line < a.out_S - j0;
+    } else {
+      po = a.out + tile_base<C::OUT_COL>(G0, a.out_S, a.out_outer_stride);
+      live = (long long)line < a.num_lines - G0;
+    }
     ls = C::OUT_COL ? 1u : (unsigned)a.out_outer_stride;
     es = C::OUT_COL ? (unsigned)a.out_S : 1u;
-    live = (long long)line < a.num_lines - G0;
     if constexpr (C::TWID == TWID_FOURSTEP_OUT) gi = (unsigned)(G0 % a.out_S) + (unsigned)line;   // column index n2 of this line
   }
 #pragma unroll

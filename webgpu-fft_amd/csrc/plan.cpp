@@ -52,10 +52,14 @@ const std::vector<LineKernelMeta>& line_kernel_registry() {
 #define LINE_PASS_B(N, R0, R1, R2, T)                                         \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, false, 2)); \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, true, false, true, 2));
+#define LINE_COL_RAGGED(N, R0, R1, R2, T)                                    \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 3)); \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, true, 3));
 #include "line_kernels.def"
 #undef LINE_ROW
 #undef LINE_PASS_A
 #undef LINE_PASS_B
+#undef LINE_COL_RAGGED
     return r;
   }();
   return reg;
@@ -375,6 +379,19 @@ struct Builder {
         st.f[0] = scale;
         st.grid = lines_grid(*m, tiles);
         ir.route += "columns[N=" + std::to_string(N) + ",S=" + std::to_string(S) + "] ";
+        return MI355FFT_OK;
+      }
+      // S not a multiple of the tile width (the packed axis 0 of an N-D r2c: S = N0/2 + 1): per-group tiles, ragged last one
+      const LineKernelMeta* mr = find_line_kernel((int)N, true, true, inverse, inverse, 3);
+      if (mr && S >= mr->T) {
+        Step& st = push(ST_LINES);
+        st.variant = mr->id;
+        st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*mr);
+        const int64_t tpg = (S + mr->T - 1) / mr->T, tiles = outer * tpg;
+        st.i[0] = tiles; st.i[1] = lines; st.i[2] = S; st.i[3] = S * N; st.i[4] = S; st.i[5] = S * N; st.i[8] = tpg;
+        st.f[0] = scale;
+        st.grid = lines_grid(*mr, tiles);
+        ir.route += "columns-ragged[N=" + std::to_string(N) + ",S=" + std::to_string(S) + "] ";
         return MI355FFT_OK;
       }
     }
