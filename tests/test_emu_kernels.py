@@ -149,7 +149,7 @@ def test_c2c_single_workgroup_long_lines(oracle, n):
     xr = oracle.random_real_batch(2 * n, 2, 0xB17 + n).reshape(-1)
     want = np.concatenate([oracle.r2c_ref_packed(xr[b * 2 * n:(b + 1) * 2 * n], 2 * n, "none") for b in range(2)])
     got, route, _ = emu.run_plan(_abi.make_desc("r2c", [2 * n], 2, "forward", "none"), xr, want.size)
-    assert route.startswith(f"lines[N={n}]"), route
+    assert route.startswith(f"lines-r2c[N={2 * n}]"), route
     check(got, want, f"r2c {2 * n} over lines {n}", 1e-5)
 
 
@@ -292,6 +292,29 @@ def test_r2c_and_c2r(oracle, n):
     check(back, x, f"c2r(r2c) round trip N={n}", 1e-5)
 
 
+@pytest.mark.parametrize("n", [128, 256, 2048, 8192])
+def test_r2c_split_fused_into_the_line_kernel(oracle, monkeypatch, n):
+    """even N with a power-of-two half length >= 64: ONE launch (line FFT of the packed pairs + split from LDS); same numbers as
+    the two-launch route"""
+    batch = 5
+    x = oracle.random_real_batch(n, batch, 0xE300 + n).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "unitary") for b in range(batch)])
+    desc = _abi.make_desc("r2c", [n], batch, "forward", "unitary")
+    got, route, launches = emu.run_plan(desc, x, want.size)
+    assert route.startswith(f"lines-r2c[N={n}]") and launches == 1, route
+    check(got, want, f"lines-r2c {n}", 1e-5)
+    back, route, launches = emu.run_plan(_abi.make_desc("c2r", [n], batch, "inverse", "unitary"), want, n * batch)
+    assert route.startswith(f"lines-c2r[N={n}]") and launches == 1, route
+    check(back, x, f"lines-c2r {n}", 1e-5)
+    monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")
+    got2, route2, launches2 = emu.run_plan(desc, x, want.size)
+    assert "r2c-split" in route2 and launches2 == 2, route2
+    check(got2, want, f"two-launch r2c {n}", 1e-5)
+    back2, route2, launches2 = emu.run_plan(_abi.make_desc("c2r", [n], batch, "inverse", "unitary"), want, n * batch)
+    assert "c2r-split" in route2 and launches2 == 2, route2
+    check(back2, x, f"two-launch c2r {n}", 1e-5)
+
+
 def test_c2r_ignores_imag_of_self_conjugate_bins(oracle):
     n = 64
     x = oracle.random_real(n, 5)
@@ -379,6 +402,7 @@ def test_c2r_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
 def test_real_four_step_solo_sizes(oracle, monkeypatch, lg, label):
     """real / Hermitian four-step with one workgroup per transform (real lines of at most 512 KB): r2c against the oracle, c2r back"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")       # 2^15 would otherwise be a single line kernel launch
     monkeypatch.setenv("MI355_EMU_CUS", "3")
     monkeypatch.setenv("MI355_EMU_MAX_GRID", "3")
     n, batch = 1 << lg, 7

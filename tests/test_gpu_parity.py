@@ -372,9 +372,13 @@ def test_c2c_ioview_and_zeropad(fft, dev, oracle):
 
 
 # ---- r2c / c2r ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 1024, 4096, 8192, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21, 17])
-def test_r2c_c2r(fft, dev, oracle, n):
-    batch = 3 if n <= 4096 else 2
+@pytest.mark.parametrize("lines_r2c", [1, 0])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 128, 1024, 4096, 8192, 1 << 15, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21, 17])
+def test_r2c_c2r(fft, dev, oracle, monkeypatch, n, lines_r2c):
+    """every r2c / c2r route by length; lines_r2c: the split fused into the line kernel (one launch, half lengths 64..16384 for
+    r2c, 2..16384 for c2r) or the two-launch route"""
+    monkeypatch.setenv("MI355FFT_LINES_R2C", str(lines_r2c))
+    batch = 37 if n <= 4096 else 2
     x = oracle.random_real_batch(n, batch, 0xE000 + n).reshape(-1)
     p = n // 2 + 1
     want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
@@ -390,6 +394,7 @@ def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     """long power-of-two r2c on both routes: XCD-fused real four-step (one launch, more transforms than groups so that
     the workspace slots alternate) and the half-length c2c + split route"""
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+    monkeypatch.setenv("MI355FFT_LINES_R2C", "0")        # 2^15 would otherwise be one line-kernel launch (tested in test_r2c_c2r)
     n = 1 << lg
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 0xE100 + lg).reshape(-1)
@@ -406,6 +411,7 @@ def test_c2r_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     """long power-of-two c2r on both routes (XCD-fused Hermitian four-step / half-length pre-split + inverse c2c):
     against the oracle's c2r of the oracle's own spectrum, and the round trip back to the signal"""
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+    monkeypatch.setenv("MI355FFT_LINES_R2C", "0")
     n = 1 << lg
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 0xE200 + lg).reshape(-1)

@@ -30,6 +30,19 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
   if (id == cur) {                                                                       \
     if constexpr ((FAM) == FAMILY) {                                                     \
       using C = LineCfg<N, R0, R1, R2, T, IC, OC, SI, SO, TW>;                           \
+      if constexpr (!(IC) && !(OC) && !(SI) && !(SO) && (TW) == 0 && C::NSTAGES >= 2) {   \
+        if (a.real_mode == 1) {                                                          \
+          l.launch(fft_lines_r2c_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          return true;                                                                   \
+        }                                                                                \
+      }                                                                                  \
+      if constexpr (!(IC) && !(OC) && (SI) && (SO) && (TW) == 0) {                        \
+        if (a.real_mode == 2) {                                                          \
+          l.launch(fft_lines_c2r_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          return true;                                                                   \
+        }                                                                                \
+      }                                                                                  \
+      if (a.real_mode != 0) return false;                                                \
       l.launch(fft_lines_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
       return true;                                                                       \
     } else return false;                                                                 \
@@ -179,7 +192,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.tw = (const cf*)ptr[2]; a.tw_lo = (const cf*)ptr[3]; a.tw_hi = (const cf*)ptr[4];
       a.num_tiles = s.i[0]; a.num_lines = s.i[1];
       a.in_S = s.i[2]; a.in_outer_stride = s.i[3]; a.out_S = s.i[4]; a.out_outer_stride = s.i[5];
-      a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7]; a.fs_group = s.i[8] ? s.i[8] : 1;
+      a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7]; a.fs_group = s.i[8] ? s.i[8] : 1; a.real_mode = (int)s.i[9];
       a.scale = s.f[0];
       const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
       return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);

@@ -70,6 +70,7 @@ struct LineArgs {
   float scale;
   int fs_shift;
   unsigned fs_lo_mask;
+  int real_mode;         // 1: fft_lines_r2c_kernel (real line read as complex pairs, split fused behind the last stage); 2: fft_lines_c2r_kernel
   long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group); COL_RAGGED: tiles per group
 };
 
@@ -307,6 +308,117 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
       stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, lo_lds);
+    }
+  }
+}
+
+// r2c of real lines of length N = 2H (H <= 16384 a power of two, H >= 64): the line is read as H complex numbers
+// z[n] = x[2n] + i x[2n+1], transformed by the ROW stages with the finished lines KEPT in LDS, and the split of the
+// half-length trick (kern_generic.hpp r2c_post_kernel: X[k] = E + wO, X[H-k] = conj(E - wO)) is applied from there: one launch,
+// 4 B read + 4 B written per real point where the two-launch route moves 12.  a.out lines have H+1 bins (a.out_outer_stride);
+// roots e^{-2 pi i k/N} = tw_hi[k >> fs_shift] * tw_lo[k & fs_lo_mask].
+template <class C>
+__global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArgs a) {
+  static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_lds = lds + C::DATA_ELEMS;
+  const int t = threadIdx.x;
+  if constexpr (C::TW_LDS_ELEMS > 0) {
+    for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+    __syncthreads();
+  }
+  constexpr int H = C::N, PER = H / 2 + 1;
+  for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    cf v[C::E];
+    stage_read<C, 0>(v, a, tile, t, lds);
+    stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
+    __syncthreads();
+    stage_read<C, 1>(v, a, tile, t, lds);
+    __syncthreads();
+    stage_compute_write<C, 1, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+    if constexpr (C::NSTAGES == 3) {
+      __syncthreads();
+      stage_read<C, 2>(v, a, tile, t, lds);
+      __syncthreads();
+      stage_compute_write<C, 2, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+    }
+    __syncthreads();
+    const long long G0 = tile * C::T;
+    const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
+    for (int p = t; p < live * PER; p += C::THREADS) {
+      const int line = p / PER, k = p - line * PER;
+      const int km = k == 0 ? 0 : H - k;
+      const cf zk = lds[lds_index<C>(line, k)], zm0 = lds[lds_index<C>(line, km)];
+      const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+      const cf zmc = {zm0.x, -zm0.y};
+      const cf e = (zk + zmc) * 0.5f;
+      const cf od = mul_neg_i((zk - zmc) * 0.5f);
+      const cf wo = cmul(w, od);
+      const cf xk = (e + wo) * a.scale;
+      cf xm = (e - wo) * a.scale;
+      xm.y = -xm.y;
+      cf* x = a.out + (G0 + line) * a.out_outer_stride;
+      x[k] = xk;
+      if (k == 0) x[H] = xm;
+      else if (km != k) x[km] = xm;
+    }
+    __syncthreads();   // LDS is re-used by the next tile
+  }
+}
+
+// c2r of packed spectra (H+1 bins per line, N = 2H) into real lines: the pre-split of the half-length trick
+// (kern_generic.hpp c2r_pre_kernel: Z[k] = E + iO, E = X[k] + conj X[H-k], O = (X[k] - conj X[H-k]) e^{+2 pi i k/N}; the
+// imaginary parts of X[0] and X[H] are ignored, real_complex.js:147-155) is applied while the first stage loads — every Z[k]
+// needs X[k] and X[H-k], two loads — and the unnormalised inverse of length H then lands x[2n] + i x[2n+1], i.e. the real
+// line, through the ordinary last-stage store.  C is the INVERSE ROW configuration (the swap trick of the c2c kernels).
+template <class C>
+__global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
+  static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_lds = lds + C::DATA_ELEMS;
+  const int t = threadIdx.x;
+  if constexpr (C::TW_LDS_ELEMS > 0) {
+    for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+    __syncthreads();
+  }
+  constexpr int H = C::N;
+  using I0 = StageInfo<C, 0>;
+  for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    cf v[C::E];
+    {
+      int line, u; thread_map<C, 0>(t, line, u);
+      const long long G0 = tile * C::T, live_lines = a.num_lines - G0;
+      const int lclamp = (long long)line < live_lines ? line : (int)live_lines - 1;
+      const cf* x = a.in + (G0 + lclamp) * a.in_outer_stride;
+#pragma unroll
+      for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < I0::R; ++q) {
+          const int k = u + b * C::TPL + q * (H / I0::R);
+          cf p = x[k], m = x[H - k];
+          if (k == 0) { p.y = 0.0f; m.y = 0.0f; }
+          const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+          const cf mc = {m.x, -m.y};
+          const cf e = p + mc;
+          const cf o = cmul_conj(p - mc, w);
+          v[b * I0::R + q] = cswap_if<true>(e + mul_pos_i(o));
+        }
+      }
+    }
+    stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
+    if constexpr (C::NSTAGES >= 2) {
+      lines_sync<C>();
+      stage_read<C, 1>(v, a, tile, t, lds);
+      lines_sync<C>();
+      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, nullptr);
+    }
+    if constexpr (C::NSTAGES == 3) {
+      lines_sync<C>();
+      stage_read<C, 2>(v, a, tile, t, lds);
+      lines_sync<C>();
+      stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, nullptr);
     }
   }
 }

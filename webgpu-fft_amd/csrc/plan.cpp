@@ -125,6 +125,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
@@ -323,6 +324,29 @@ struct Builder {
     if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;   // as emit_axis: two co-resident workgroups per CU
     st.grid = (unsigned)grid;
     ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    return true;
+  }
+
+  // r2c of dense real lines of length N = 2H, H a power of two in 64..max_line: the ROW line kernel of length H with the split
+  // fused behind its last stage (one launch instead of FFT + r2c_post_kernel)
+  // (c2r: the mirror — the pre-split rides the first-stage loads of the INVERSE line kernel, any power-of-two half length >= 2)
+  bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false) {
+    const int64_t H = N / 2;
+    if (opt.force_generic || !opt.lines_r2c || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;   // xcd_fused == 2: emulation tests of the fused instances
+    const LineKernelMeta* m = find_line_kernel((int)H, false, false, c2r, c2r, 0);
+    if (!m || (!c2r && m->lds_bytes == 0)) return false;
+    std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));
+    for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
+    for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
+    Step& st = push(ST_LINES);
+    st.variant = m->id;
+    st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m); st.p[3] = add_table(lo); st.p[4] = add_table(hi);
+    const int64_t tiles = (lines + m->T - 1) / m->T;
+    st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = c2r ? H + 1 : H; st.i[4] = 1; st.i[5] = c2r ? H : H + 1; st.i[6] = 10; st.i[7] = 1023;
+    st.i[9] = c2r ? 2 : 1;
+    st.f[0] = scale;
+    st.grid = lines_grid(*m, tiles);
+    ir.route += std::string(c2r ? "lines-c2r[N=" : "lines-r2c[N=") + std::to_string(N) + "] ";
     return true;
   }
 
@@ -950,7 +974,9 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   const PtrRef user_out(BUF_OUTPUT, 0);
   PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
   PtrRef out = side_output_target(d, b, user_out, pshape, false, b.ir.out_bytes);
-  if (b.emit_xcd_r2c(in, out, N, lines, scale)) {
+  if (b.emit_lines_r2c(in, out, N, lines, scale)) {
+    // one launch: line FFT of the packed pairs with the split fused behind its last stage (kern_lines.hpp fft_lines_r2c_kernel)
+  } else if (b.emit_xcd_r2c(in, out, N, lines, scale)) {
     // one persistent launch: real four-step (kern_xcd_real.hpp)
   } else if (N % 2 == 0) {
     const int64_t H = N / 2;
@@ -1009,7 +1035,9 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     int rc = b.emit_nd(packed, packed, ps, d.rank, d.batch, true, 1.0f, err, 1);
     if (rc) return rc;
   }
-  if (b.emit_xcd_r2c(packed, out, N, lines, scale, true)) {
+  if (b.emit_lines_r2c(packed, out, N, lines, scale, true)) {
+    // one launch: the pre-split applied by the first-stage loads of the inverse line kernel (kern_lines.hpp fft_lines_c2r_kernel)
+  } else if (b.emit_xcd_r2c(packed, out, N, lines, scale, true)) {
     // one persistent launch: Hermitian four-step (kern_xcd_real.hpp)
   } else if (N % 2 == 0) {
     const int64_t H = N / 2;
