@@ -303,9 +303,11 @@ def test_r2c_split_fused_into_the_line_kernel(oracle, monkeypatch, n):
     got, route, launches = emu.run_plan(desc, x, want.size)
     assert route.startswith(f"lines-r2c[N={n}]") and launches == 1, route
     check(got, want, f"lines-r2c {n}", 1e-5)
+    monkeypatch.setenv("MI355_EMU_LINES_C2R", "1")       # the c2r twin exists but is off by default (slower on the hardware)
     back, route, launches = emu.run_plan(_abi.make_desc("c2r", [n], batch, "inverse", "unitary"), want, n * batch)
     assert route.startswith(f"lines-c2r[N={n}]") and launches == 1, route
     check(back, x, f"lines-c2r {n}", 1e-5)
+    monkeypatch.setenv("MI355_EMU_LINES_C2R", "0")
     monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")
     got2, route2, launches2 = emu.run_plan(desc, x, want.size)
     assert "r2c-split" in route2 and launches2 == 2, route2

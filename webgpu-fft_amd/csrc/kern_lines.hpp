@@ -404,7 +404,8 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
           const cf e = p + mc;
           const cf o = cmul_conj(p - mc, w);
           v[b * I0::R + q] = cswap_if<true>(e + mul_pos_i(o));
-        }
+          if ((q & 7) == 7) MI_SCHED_FENCE();      // caps the loads in flight (4 per element): without it the kernel takes
+        }                                          // 256 VGPRs and a quarter of the line kernel's occupancy
       }
     }
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);

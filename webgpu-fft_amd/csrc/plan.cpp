@@ -126,6 +126,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_LINES_C2R")) o.lines_c2r = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
@@ -332,7 +333,7 @@ struct Builder {
   // (c2r: the mirror — the pre-split rides the first-stage loads of the INVERSE line kernel, any power-of-two half length >= 2)
   bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false) {
     const int64_t H = N / 2;
-    if (opt.force_generic || !opt.lines_r2c || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;   // xcd_fused == 2: emulation tests of the fused instances
+    if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;   // xcd_fused == 2: emulation tests of the fused instances
     const LineKernelMeta* m = find_line_kernel((int)H, false, false, c2r, c2r, 0);
     if (!m || (!c2r && m->lds_bytes == 0)) return false;
     std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));
