@@ -369,9 +369,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
 
 // c2r of packed spectra (H+1 bins per line, N = 2H) into real lines: the pre-split of the half-length trick
 // (kern_generic.hpp c2r_pre_kernel: Z[k] = E + iO, E = X[k] + conj X[H-k], O = (X[k] - conj X[H-k]) e^{+2 pi i k/N}; the
-// imaginary parts of X[0] and X[H] are ignored, real_complex.js:147-155) is applied while the first stage loads — every Z[k]
-// needs X[k] and X[H-k], two loads — and the unnormalised inverse of length H then lands x[2n] + i x[2n+1], i.e. the real
-// line, through the ordinary last-stage store.  C is the INVERSE ROW configuration (the swap trick of the c2c kernels).
+// imaginary parts of X[0] and X[H] are ignored, real_complex.js:147-155) is applied in LDS before the first stage (directly
+// in the first-stage loads for single-stage lines), and the unnormalised inverse of length H then lands x[2n] + i x[2n+1], i.e.
+// the real line, through the ordinary last-stage store.  C is the INVERSE ROW configuration (the swap trick of the c2c kernels).
 template <class C>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
@@ -390,22 +390,54 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
     {
       int line, u; thread_map<C, 0>(t, line, u);
       const long long G0 = tile * C::T, live_lines = a.num_lines - G0;
-      const int lclamp = (long long)line < live_lines ? line : (int)live_lines - 1;
-      const cf* x = a.in + (G0 + lclamp) * a.in_outer_stride;
-#pragma unroll
-      for (int b = 0; b < I0::NB; ++b) {
-#pragma unroll
-        for (int q = 0; q < I0::R; ++q) {
-          const int k = u + b * C::TPL + q * (H / I0::R);
-          cf p = x[k], m = x[H - k];
-          if (k == 0) { p.y = 0.0f; m.y = 0.0f; }
+      const int live = (int)(live_lines < (long long)C::T ? live_lines : (long long)C::T);
+      const int lclamp = line < live ? line : live - 1;
+      if constexpr (C::NSTAGES >= 2) {
+        // through LDS: (1) the packed lines, every bin read once and coalesced; (2) the pre-split in place, one lane per pair
+        // (k, H-k) — the r2c kernel's post-pass in reverse, a few registers per lane; (3) the first stage picks its inputs up
+        static_assert(C::PITCH >= H + 1, "a packed line fits a line slot");
+        constexpr int PER = H / 2 + 1;
+        for (int p = t; p < live * (H + 1); p += C::THREADS) {
+          const int l = p / (H + 1), k = p - l * (H + 1);
+          lds[l * C::PITCH + k] = a.in[(G0 + l) * a.in_outer_stride + k];
+        }
+        __syncthreads();
+        for (int p = t; p < live * PER; p += C::THREADS) {
+          const int l = p / PER, k = p - l * PER;
+          cf* xl = lds + l * C::PITCH;
+          cf pk = xl[k], m = xl[H - k];
+          if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
           const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
           const cf mc = {m.x, -m.y};
-          const cf e = p + mc;
-          const cf o = cmul_conj(p - mc, w);
-          v[b * I0::R + q] = cswap_if<true>(e + mul_pos_i(o));
-          if ((q & 7) == 7) MI_SCHED_FENCE();      // caps the loads in flight (4 per element): without it the kernel takes
-        }                                          // 256 VGPRs and a quarter of the line kernel's occupancy
+          const cf e = pk + mc;
+          const cf o = cmul_conj(pk - mc, w);
+          xl[k] = e + mul_pos_i(o);
+          if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
+        }
+        __syncthreads();
+        const cf* zl = lds + lclamp * C::PITCH;
+#pragma unroll
+        for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+          for (int q = 0; q < I0::R; ++q) v[b * I0::R + q] = cswap_if<true>(zl[u + b * C::TPL + q * (H / I0::R)]);
+        }
+        __syncthreads();   // everyone has its inputs before stage 0 re-uses the buffer
+      } else {
+        const cf* x = a.in + (G0 + lclamp) * a.in_outer_stride;
+#pragma unroll
+        for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+          for (int q = 0; q < I0::R; ++q) {
+            const int k = u + b * C::TPL + q * (H / I0::R);
+            cf p = x[k], m = x[H - k];
+            if (k == 0) { p.y = 0.0f; m.y = 0.0f; }
+            const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+            const cf mc = {m.x, -m.y};
+            const cf e = p + mc;
+            const cf o = cmul_conj(p - mc, w);
+            v[b * I0::R + q] = cswap_if<true>(e + mul_pos_i(o));
+          }
+        }
       }
     }
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
