@@ -1,27 +1,32 @@
-// kern_xcd.hpp — XCD-fused four-step: both passes of an N = N1*N2 transform in ONE persistent launch, the 32
-// workgroups that share an XCD (one per CU) working on one transform at a time.
+// kern_xcd.hpp — fused two-pass transforms: both passes of an N = N1*N2 four-step (or of a 2-D plane) in ONE persistent launch.
 //
 // Why (profiles/r01_xcd_fused_ab.log): the two-kernel route runs the whole chip in lock-step (all CUs
-// load, then all compute, then all store, one launch pair per chunk).  Here groups of workgroups that share an L2 walk
-// the batch independently, drift out of phase with each other and keep the fabric busy in both directions; the
-// intermediate of a transform lives in a small per-group workspace slot that is re-used for every transform.
-// Measured at N = 2^20: 186 GPoints/s against 155 for the two-kernel route.  (The intermediate still crosses the fabric
-// twice — 8 MiB per transform does not survive in a 4 MiB L2 — see the PMC summary under profiles/.)
+// load, then all compute, then all store, one launch pair per chunk).  Here groups of workgroups walk the batch
+// independently, drift out of phase with each other and keep the fabric busy in both directions; the intermediate of a
+// transform lives in a small per-group workspace slot that is re-used for every transform.  Measured at N = 2^20: 186
+// GPoints/s against 155 for the two-kernel route.  (The intermediate still crosses the fabric twice — 8 MiB per transform
+// does not survive in a 4 MiB L2 — see the PMC summary under profiles/.)
 //
-// Structure per launch (grid = one workgroup per CU, LDS-limited):
-//   registration: every workgroup reads its XCC id, takes a rank inside that XCD and waits (bounded) until all
-//                 gridDim.x workgroups have registered; groups = the XCDs that received workgroups.  Nothing assumes a
-//                 placement: a group is BY CONSTRUCTION the set of workgroups behind one L2.
-//   per transform t (group g takes t = g, g+G, ...):
-//     phase A  column tiles r, r+s, ... of x_t -> W[xcc]      (kern_lines.hpp PASS_A stages)
-//     XCD barrier
-//     phase B  row tiles r, r+s, ... of W[xcc] -> out_t       (PASS_B stages, four-step roots generated per tile)
-//   (W[xcc] is double-buffered, so the A/B barrier of the next transform is the only one needed)
-// Hand-off protocol (same-XCD by construction, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"): producers'
-// stores are complete in the shared L2 after `s_waitcnt vmcnt(0)`; one lane per workgroup adds to the group's monotonic
-// counter and polls it with relaxed agent-scope loads; every consumer workgroup then invalidates its CU's L1 with an
-// agent-scope acquire before reading.  No L2 write-back is needed because producer and consumer share that L2.
-// Every spin is bounded: on a timeout the workgroup raises a sticky error word and returns (queue_wait reports it).
+// Modes:
+//   shared (transforms > 1 MiB)  the workgroups of one XCD — one per CU, two where 256 threads and <= 80 KB of LDS leave room —
+//                 are divided into `split` groups; a group works on one transform at a time:
+//                   registration: every workgroup reads its XCC id, takes a rank inside that XCD and waits (bounded) until all
+//                                 gridDim.x workgroups have registered.  Nothing assumes a placement: a group is BY
+//                                 CONSTRUCTION a set of workgroups behind one L2.
+//                   per transform t (group g takes t = g, g+G, ...):
+//                     phase A  column tiles r, r+s, ... of x_t -> W      (kern_lines.hpp PASS_A stages)
+//                     group barrier
+//                     phase B  row tiles r, r+s, ... of W -> out_t       (PASS_B stages, four-step roots generated per tile;
+//                                                                         TWO_D: ROW stages, natural order, no roots)
+//                   (W is double-buffered, so the A/B barrier of the next transform is the only one needed)
+//                 Hand-off protocol (same-XCD by construction, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"):
+//                 producers' stores are complete in the shared L2 after `s_waitcnt vmcnt(0)`; one lane per workgroup adds to
+//                 the group's monotonic counter and polls it with relaxed agent-scope loads; every consumer workgroup then
+//                 invalidates its CU's L1 with an agent-scope acquire before reading.  No L2 write-back is needed because
+//                 producer and consumer share that L2.  Every spin is bounded: on a timeout the workgroup raises a sticky
+//                 error word and returns (queue_wait reports it).  All workgroups must be co-resident.
+//   solo (transforms <= 1 MiB)  every workgroup walks whole transforms alone: phase A into its own slot, a workgroup barrier
+//                 + L1 invalidate, phase B out of it.  No registration, no cross-workgroup synchronisation, any grid size.
 #pragma once
 #include "kern_lines.hpp"
 
