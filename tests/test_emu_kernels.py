@@ -303,7 +303,7 @@ def test_r2c_split_fused_into_the_line_kernel(oracle, monkeypatch, n):
     got, route, launches = emu.run_plan(desc, x, want.size)
     assert route.startswith(f"lines-r2c[N={n}]") and launches == 1, route
     check(got, want, f"lines-r2c {n}", 1e-5)
-    monkeypatch.setenv("MI355_EMU_LINES_C2R", "2")       # the c2r twin is used up to N = 1024 by default; 2 forces it for every length
+    monkeypatch.setenv("MI355_EMU_LINES_C2R", "2")       # the c2r twin is used up to N = 2^14 by default; 2 forces it for every length
     back, route, launches = emu.run_plan(_abi.make_desc("c2r", [n], batch, "inverse", "unitary"), want, n * batch)
     assert route.startswith(f"lines-c2r[N={n}]") and launches == 1, route
     check(back, x, f"lines-c2r {n}", 1e-5)

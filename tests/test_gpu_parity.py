@@ -378,7 +378,7 @@ def test_r2c_c2r(fft, dev, oracle, monkeypatch, n, lines_r2c):
     """every r2c / c2r route by length; lines_r2c: the split fused into the line kernel (one launch, half lengths 64..16384 for
     r2c, 2..16384 for c2r) or the two-launch route"""
     monkeypatch.setenv("MI355FFT_LINES_R2C", str(lines_r2c))
-    monkeypatch.setenv("MI355FFT_LINES_C2R", str(2 * lines_r2c))  # 2: the c2r twin for every length (default: N <= 1024 only)
+    monkeypatch.setenv("MI355FFT_LINES_C2R", str(2 * lines_r2c))  # 2: the c2r twin for every length (default: N <= 2^14)
     batch = 37 if n <= 4096 else 2
     x = oracle.random_real_batch(n, batch, 0xE000 + n).reshape(-1)
     p = n // 2 + 1

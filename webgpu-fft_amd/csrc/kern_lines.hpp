@@ -393,19 +393,16 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
       const int live = (int)(live_lines < (long long)C::T ? live_lines : (long long)C::T);
       const int lclamp = line < live ? line : live - 1;
       if constexpr (C::NSTAGES >= 2) {
-        // through LDS: (1) the packed lines, every bin read once and coalesced; (2) the pre-split in place, one lane per pair
-        // (k, H-k) — the r2c kernel's post-pass in reverse, a few registers per lane; (3) the first stage picks its inputs up
+        // through LDS: one lane per pair (k, H-k) reads the two bins (every bin read once, forward and mirrored runs), forms
+        // Z[k] and Z[H-k] — the r2c kernel's post-pass in reverse, a few registers per lane — and drops them into the line slot;
+        // the first stage then picks its inputs up
         static_assert(C::PITCH >= H + 1, "a packed line fits a line slot");
         constexpr int PER = H / 2 + 1;
-        for (int p = t; p < live * (H + 1); p += C::THREADS) {
-          const int l = p / (H + 1), k = p - l * (H + 1);
-          lds[l * C::PITCH + k] = a.in[(G0 + l) * a.in_outer_stride + k];
-        }
-        __syncthreads();
         for (int p = t; p < live * PER; p += C::THREADS) {
           const int l = p / PER, k = p - l * PER;
+          const cf* x = a.in + (G0 + l) * a.in_outer_stride;
           cf* xl = lds + l * C::PITCH;
-          cf pk = xl[k], m = xl[H - k];
+          cf pk = x[k], m = x[H - k];
           if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
           const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
           const cf mc = {m.x, -m.y};

@@ -334,7 +334,7 @@ struct Builder {
   bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false) {
     const int64_t H = N / 2;
     if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;
-    if (c2r && H > 512 && opt.lines_c2r != 2) return false;      // measured: the LDS pre-split only pays for short lines   // xcd_fused == 2: emulation tests of the fused instances
+    if (c2r && H > 8192 && opt.lines_c2r != 2) return false;     // N = 2^15: the Hermitian four-step in solo mode measured faster (322 vs 304)   // xcd_fused == 2: emulation tests of the fused instances
     const LineKernelMeta* m = find_line_kernel((int)H, false, false, c2r, c2r, 0);
     if (!m || (!c2r && m->lds_bytes == 0)) return false;
     std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));

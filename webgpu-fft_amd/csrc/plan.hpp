@@ -118,9 +118,8 @@ struct PlannerOptions {
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
-  int lines_c2r = 1;                   // c2r twin (pre-split in LDS before the first stage): used for half lengths <= 512 (N = 256: 320 vs
-                                       // 132 G real points/s, 1024: 296 vs 243); longer lines measured slower than the two-launch
-                                       // route (4096: 180 vs 251, 2^14: 229 vs 269); 2 forces it for every length (tests)
+  int lines_c2r = 1;                   // c2r twin (pair pre-split from global into LDS before the first stage): half lengths <= 8192
+                                       // (N = 256: 528 vs 133 G real points/s, 1024: 471 vs 243, 2^14: 312 vs 270); 2 forces it at 2^15 too
   int lines_r2c = 1;                   // r2c with a half length of 64..max_line: split fused into the line kernel
   int max_line = 16384;                // longest power-of-two line given to a single workgroup (4096: N = 8192, 16384 take the four-step routes)
   int mixed_lines = 1;                 // mixed-radix lengths <= 4096: one LDS line kernel instead of one global pass per radix
