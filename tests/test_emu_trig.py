@@ -29,6 +29,36 @@ def test_trig_1d(oracle, typ, n):
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, (typ, n, direction, route)
 
 
+@pytest.mark.parametrize("typ", ["dct2", "dct3", "dst2", "dst3"])
+@pytest.mark.parametrize("n,fused,backend", [(4, "1", "r2c-split"), (100, "1", "r2c-split"), (256, "1", "lines-r2c"), (4096, "1", "lines-r2c"),
+                                             (4096, "2", "xcd-r2c")])
+def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
+    """dct2/dst2/dct3/dst3 along a dense even axis: Makhoul permutation + a real FFT of length N (kern_trig.hpp kinds 8..11) over each
+    r2c / c2r back-end; the general 2N route (MI355_EMU_TRIG_REAL=0) must agree with it"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", fused)
+    if fused == "2":
+        monkeypatch.setenv("MI355_EMU_CUS", "4")
+        monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")
+        monkeypatch.setenv("MI355_EMU_LINES_C2R", "0")
+    batch = 2
+    x = oracle.random_real_batch(n, batch, 0x7B16 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc, _ = _desc({"type": typ, "shape": [n], "batch": batch, "direction": direction, "normalize": "unitary", "layout": {"interleavedComplex": False}})
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert route.startswith("trig-real[") and ("r2c" in route or "c2r" in route) and "trig[" not in route, route
+        if direction == "forward" and typ in ("dct2", "dst2"):
+            assert backend in route, route
+        want = oracle.trig_ref_batch(x, [n], batch, typ, direction, "unitary")
+        scale = max(1.0, float(np.max(np.abs(want))))
+        assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, (typ, n, direction, route)
+        if n <= 256:
+            monkeypatch.setenv("MI355_EMU_TRIG_REAL", "0")
+            old, route0, _ = emu.run_plan(desc, x, x.size)
+            monkeypatch.delenv("MI355_EMU_TRIG_REAL")
+            assert "trig[" in route0 and "trig-real" not in route0, route0
+            assert float(np.max(np.abs(got.astype(np.float64) - old))) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("typ", ["dct2", "dst3", "dct1", "dst4"])
 def test_trig_nd(oracle, typ):
     shape, batch = [8, 5, 4], 2

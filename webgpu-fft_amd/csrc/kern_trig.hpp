@@ -1,5 +1,6 @@
 // kern_trig.hpp — DCT-I..IV / DST-I..IV as a complex FFT of length L with a pre- and a post-pass per axis (SURVEY.md 8f rank 4;
-// replaces src/runtime/plans/dct_fft.js for the real, f32 case).  Completeness route: three launches + one FFT per axis.
+// replaces src/runtime/plans/dct_fft.js for the real, f32 case).  General route: three launches + one FFT of length L per axis;
+// dct2/dst2/dct3/dst3 along a dense axis of even length take the real-FFT route at the end of this file.
 //
 // kind (the typeKind table of dct_fft.js:48-57; dct3 / dst3 are dct2 / dst2 with the directions exchanged), theta = pi/(2N):
 //   0 dct1      L = 2(N-1)  z = even extension of x                         X[k] = Re Z[k]
@@ -80,6 +81,54 @@ static __global__ void __launch_bounds__(256) trig_post_kernel(const TrigArgs a)
       case 7: { const cf w = trig_phase(-((double)k + 0.5) * inv2n); const cf v = Z[k]; r = -(v.x * w.y + v.y * w.x); } break;
     }
     a.y[base + k * a.S] = r * a.scale;
+  }
+}
+
+// ---- dct2 / dst2 / dct3 / dst3 over dense lines (S = 1) of even length: a REAL FFT of length N instead of a complex one of 2N ----
+// Makhoul's permutation v[n] = x[2n], v[N-1-n] = x[2n+1] (n < N/2) turns the DCT-II sum into V = FFT_N(v) and one phase:
+//   t_k = e^{-i theta k} V[k]:   X[k] = Re t_k,   X[N-k] = -Im t_k      (k = 0..N/2, V from the r2c route: N/2+1 bins)
+// and back (dct3, unnormalised as kind 2):   V[k] = (X[k] - i X[N-k]) e^{+i theta k} / 2, X[N] := 0;  v = c2r_N(V), un-permuted.
+// dst2(x)[k] = dct2((-1)^n x)[N-1-k] and dst3(X)[n] = (-1)^n dct3(reversed X)[n]: the sine kinds ride the same two passes
+// with a sign on the odd samples and reversed bins.  Four times less FFT work and a quarter of the intermediate bytes.
+//   kind 8 dct2 fwd, 9 dst2 fwd (pre: x -> y = v, real;  post: z = V packed [line][L = N/2+1] -> y)
+//   kind 10 dct2 inv, 11 dst2 inv (pre: x -> z = V packed;  post: x = v, real -> y)
+static __global__ void __launch_bounds__(256) trig_real_pre_kernel(const TrigArgs a) {
+  const bool fwd = a.kind < 10, sine = a.kind & 1;
+  const long long per = fwd ? a.N : a.L, total = a.lines * per;
+  const double inv2n = 1.0 / (2.0 * (double)a.N);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long G = g / per, m = g - G * per;
+    const float* x = a.x + G * a.N;
+    if (fwd) {
+      const long long n = m < a.N / 2 ? 2 * m : 2 * (a.N - 1 - m) + 1;
+      const float v = x[n];
+      a.y[g] = (sine && (n & 1)) ? -v : v;
+    } else {
+      const float re = sine ? x[a.N - 1 - m] : x[m];
+      const float im = m == 0 ? 0.0f : (sine ? x[m - 1] : x[a.N - m]);
+      const cf w = trig_phase((double)m * inv2n);
+      cf v; v.x = 0.5f * (re * w.x + im * w.y); v.y = 0.5f * (re * w.y - im * w.x);
+      a.z[g] = v;
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256) trig_real_post_kernel(const TrigArgs a) {
+  const bool fwd = a.kind < 10, sine = a.kind & 1;
+  const long long per = fwd ? a.L : a.N, total = a.lines * per;
+  const double inv2n = 1.0 / (2.0 * (double)a.N);
+  for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const long long G = g / per, m = g - G * per;
+    float* y = a.y + G * a.N;
+    if (fwd) {
+      const cf w = trig_phase(-(double)m * inv2n), v = a.z[g];
+      const float re = (v.x * w.x - v.y * w.y) * a.scale, im = -(v.x * w.y + v.y * w.x) * a.scale;
+      y[sine ? a.N - 1 - m : m] = re;
+      if (m > 0 && 2 * m != a.N) y[sine ? m - 1 : a.N - m] = im;
+    } else {
+      const float v = a.x[G * a.N + ((m & 1) ? a.N - 1 - (m >> 1) : (m >> 1))];
+      y[m] = ((sine && (m & 1)) ? -v : v) * a.scale;
+    }
   }
 }
 

@@ -127,6 +127,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_C2R")) o.lines_c2r = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_TRIG_REAL")) o.trig_real = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
@@ -350,6 +351,42 @@ struct Builder {
     st.grid = lines_grid(*m, tiles);
     ir.route += std::string(c2r ? "lines-c2r[N=" : "lines-r2c[N=") + std::to_string(N) + "] ";
     return true;
+  }
+
+  // 1-D r2c of `lines` dense real lines of even length N into packed spectra (N/2+1 bins): fused line kernel, real four-step,
+  // or the half-length complex FFT + split
+  int emit_r2c_even(PtrRef in, PtrRef out, int64_t N, int64_t lines, float scale, std::string& err) {
+    if (emit_lines_r2c(in, out, N, lines, scale)) return MI355FFT_OK;   // one launch: split fused behind the last stage (fft_lines_r2c_kernel)
+    if (emit_xcd_r2c(in, out, N, lines, scale)) return MI355FFT_OK;     // one persistent launch: real four-step (kern_xcd_real.hpp)
+    const int64_t H = N / 2, P = H + 1;
+    PtrRef z = alloc_work((uint64_t)lines * H * 8);
+    // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]
+    int rc = emit_axis(in, z, H, 1, lines, false, 1.0f, err);
+    if (rc) return rc;
+    Step& st = push(ST_R2C_POST);
+    st.p[0] = z; st.p[1] = out;
+    split_roots(st, N, H / 2 + 1);
+    st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
+    st.grid = generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
+    ir.route += "r2c-split ";
+    return MI355FFT_OK;
+  }
+  // the mirror: packed spectra -> real lines (unnormalised inverse times `scale`)
+  int emit_c2r_even(PtrRef packed, PtrRef out, int64_t N, int64_t lines, float scale, std::string& err) {
+    if (emit_lines_r2c(packed, out, N, lines, scale, true)) return MI355FFT_OK;   // pre-split in the first-stage loads (fft_lines_c2r_kernel)
+    if (emit_xcd_r2c(packed, out, N, lines, scale, true)) return MI355FFT_OK;     // Hermitian four-step (kern_xcd_real.hpp)
+    const int64_t H = N / 2, P = H + 1;
+    PtrRef z = alloc_work((uint64_t)lines * H * 8);
+    Step& st = push(ST_C2R_PRE);
+    st.p[0] = packed; st.p[1] = z;
+    split_roots(st, N, H / 2 + 1);
+    st.i[0] = H; st.i[1] = lines; st.i[2] = P;
+    st.grid = generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
+    // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
+    int rc = emit_axis(z, out, H, 1, lines, true, scale, err);
+    if (rc) return rc;
+    ir.route += "c2r-split ";
+    return MI355FFT_OK;
   }
 
   // Lane layouts (channel-lane presets, whdcn with unit stride along the line): contiguous power-of-two lines that sit at
@@ -976,22 +1013,9 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   const PtrRef user_out(BUF_OUTPUT, 0);
   PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
   PtrRef out = side_output_target(d, b, user_out, pshape, false, b.ir.out_bytes);
-  if (b.emit_lines_r2c(in, out, N, lines, scale)) {
-    // one launch: line FFT of the packed pairs with the split fused behind its last stage (kern_lines.hpp fft_lines_r2c_kernel)
-  } else if (b.emit_xcd_r2c(in, out, N, lines, scale)) {
-    // one persistent launch: real four-step (kern_xcd_real.hpp)
-  } else if (N % 2 == 0) {
-    const int64_t H = N / 2;
-    PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
-    // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]
-    int rc = b.emit_axis(in, z, H, 1, lines, false, 1.0f, err);
+  if (N % 2 == 0) {
+    const int rc = b.emit_r2c_even(in, out, N, lines, scale, err);
     if (rc) return rc;
-    Step& st = b.push(ST_R2C_POST);
-    st.p[0] = z; st.p[1] = out;
-    b.split_roots(st, N, H / 2 + 1);
-    st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
-    b.ir.route += "r2c-split ";
   } else {
     PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
     Step& e = b.push(ST_REAL_TO_COMPLEX);
@@ -1037,22 +1061,9 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     int rc = b.emit_nd(packed, packed, ps, d.rank, d.batch, true, 1.0f, err, 1);
     if (rc) return rc;
   }
-  if (b.emit_lines_r2c(packed, out, N, lines, scale, true)) {
-    // one launch: the pre-split applied by the first-stage loads of the inverse line kernel (kern_lines.hpp fft_lines_c2r_kernel)
-  } else if (b.emit_xcd_r2c(packed, out, N, lines, scale, true)) {
-    // one persistent launch: Hermitian four-step (kern_xcd_real.hpp)
-  } else if (N % 2 == 0) {
-    const int64_t H = N / 2;
-    PtrRef z = b.alloc_work((uint64_t)lines * H * 8);
-    Step& st = b.push(ST_C2R_PRE);
-    st.p[0] = packed; st.p[1] = z;
-    b.split_roots(st, N, H / 2 + 1);
-    st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = b.generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
-    // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
-    int rc = b.emit_axis(z, out, H, 1, lines, true, scale, err);
+  if (N % 2 == 0) {
+    const int rc = b.emit_c2r_even(packed, out, N, lines, scale, err);
     if (rc) return rc;
-    b.ir.route += "c2r-split ";
   } else {
     PtrRef full = b.alloc_work((uint64_t)lines * N * 8);
     Step& u = b.push(ST_UNPACK_HERM);
@@ -1098,11 +1109,37 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   PtrRef cur = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
   const PtrRef dst = side_output_target(d, b, user_out, d.shape, true, b.ir.out_bytes);
   int64_t S = 1;
+  int general_axes = 0;
   for (int a = 0; a < rank; ++a) {
     const int64_t N = d.shape[a], lines = d.batch * (n / N);
     const int64_t L = kind == 0 ? 2 * (N - 1) : (kind == 4 ? 2 * (N + 1) : 2 * N);
     const uint64_t mark = b.work_top;
+    if (b.opt.trig_real && !b.opt.force_generic && S == 1 && N % 2 == 0 && N >= 4 && (kind == 1 || kind == 2 || kind == 5 || kind == 6)) {
+      // dense even lines: real FFT of length N behind Makhoul's permutation (kern_trig.hpp kinds 8..11)
+      const bool tfwd = kind == 1 || kind == 5;
+      const int rkind = (tfwd ? 8 : 10) + (kind >= 5 ? 1 : 0);
+      const int64_t P = N / 2 + 1;
+      const PtrRef v = b.alloc_work((uint64_t)lines * N * 4), V = b.alloc_work((uint64_t)lines * P * 8);
+      const float last = a == rank - 1 ? scale : 1.0f;
+      Step& pre = b.push(ST_TRIG_PRE);
+      pre.p[0] = cur; pre.p[1] = V; pre.p[2] = v;
+      pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = 1; pre.i[4] = rkind;
+      pre.grid = b.generic_grid(lines * (tfwd ? N : P));
+      b.ir.route += "trig-real[kind=" + std::to_string(kind) + "] ";
+      const int rc = tfwd ? b.emit_r2c_even(v, V, N, lines, 1.0f, err) : b.emit_c2r_even(V, v, N, lines, 1.0f, err);
+      if (rc) return rc;
+      Step& post = b.push(ST_TRIG_POST);
+      post.p[0] = v; post.p[1] = V; post.p[2] = dst;
+      post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = 1; post.i[4] = rkind;
+      post.f[0] = last;
+      post.grid = b.generic_grid(lines * (tfwd ? P : N));
+      b.work_top = mark;
+      cur = dst;
+      S *= N;
+      continue;
+    }
     const PtrRef z = b.alloc_work((uint64_t)lines * L * 8);
+    ++general_axes;
     Step& pre = b.push(ST_TRIG_PRE);
     pre.p[0] = cur; pre.p[1] = z; pre.p[2] = dst;
     pre.i[0] = lines; pre.i[1] = N; pre.i[2] = L; pre.i[3] = S; pre.i[4] = kind;
@@ -1118,7 +1155,7 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     cur = dst;
     S *= N;
   }
-  b.ir.route += "trig[kind=" + std::to_string(kind) + "] ";
+  if (general_axes) b.ir.route += "trig[kind=" + std::to_string(kind) + "] ";
   return finish_side_output(d, b, user_out, dst, d.shape, true, err);
 }
 

@@ -118,6 +118,7 @@ struct PlannerOptions {
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
+  int trig_real = 1;                   // dct2/dst2/dct3/dst3 along a dense even axis through a real FFT of length N (kern_trig.hpp)
   int lines_c2r = 1;                   // c2r twin (pair pre-split from global into LDS before the first stage): half lengths <= 8192
                                        // (N = 256: 528 vs 133 G real points/s, 1024: 471 vs 243, 2^14: 312 vs 270); 2 forces it at 2^15 too
   int lines_r2c = 1;                   // r2c with a half length of 64..max_line: split fused into the line kernel
