@@ -29,12 +29,13 @@ def test_trig_1d(oracle, typ, n):
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, (typ, n, direction, route)
 
 
-@pytest.mark.parametrize("typ", ["dct2", "dct3", "dst2", "dst3"])
+@pytest.mark.parametrize("typ", TYPES)
 @pytest.mark.parametrize("n,fused,backend", [(4, "1", "r2c-split"), (100, "1", "r2c-split"), (256, "1", "lines-r2c"), (4096, "1", "lines-r2c"),
                                              (4096, "2", "xcd-r2c")])
 def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
-    """dct2/dst2/dct3/dst3 along a dense even axis: Makhoul permutation + a real FFT of length N (kern_trig.hpp kinds 8..11) over each
-    r2c / c2r back-end; the general 2N route (MI355_EMU_TRIG_REAL=0) must agree with it"""
+    """dense axis 0 (kern_trig.hpp kinds 8..15): dct2/dst2/dct3/dst3 as Makhoul permutation + a real FFT of length N over each
+    r2c / c2r back-end, dct4/dst4 as a complex FFT of N/2, dct1/dst1 as the r2c of the real extension; the general 2N route
+    (MI355_EMU_TRIG_REAL=0) must agree with all of them"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", fused)
     if fused == "2":
         monkeypatch.setenv("MI355_EMU_CUS", "4")
@@ -45,7 +46,8 @@ def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
     for direction in ("forward", "inverse"):
         desc, _ = _desc({"type": typ, "shape": [n], "batch": batch, "direction": direction, "normalize": "unitary", "layout": {"interleavedComplex": False}})
         got, route, _ = emu.run_plan(desc, x, x.size)
-        assert route.startswith("trig-real[") and ("r2c" in route or "c2r" in route) and "trig[" not in route, route
+        assert route.startswith("trig-real[") and "trig[" not in route, route
+        assert ("r2c" in route or "c2r" in route) == (typ[3] != "4"), route
         if direction == "forward" and typ in ("dct2", "dst2"):
             assert backend in route, route
         want = oracle.trig_ref_batch(x, [n], batch, typ, direction, "unitary")

@@ -650,13 +650,13 @@ def test_dct_dst(fft, dev, oracle, typ):
             assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-4 * scale, (typ, shape, direction, route)
 
 
-@pytest.mark.parametrize("typ", ["dct2", "dct3", "dst2", "dst3"])
+@pytest.mark.parametrize("typ", ["dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"])
 @pytest.mark.parametrize("lg", [13, 16, 20])
 def test_dct_dst_real_fft_route_long(fft, dev, oracle, monkeypatch, typ, lg):
-    """long dense lines take the real-FFT route (kern_trig.hpp kinds 8..11) over lines-r2c / the real four-step; too long for the
+    """long dense lines take the real-FFT route (kern_trig.hpp kinds 8..15) over lines-r2c / the real four-step; too long for the
     O(N^2) oracle, so: agreement with the general 2N-point route (itself oracle-checked above) and with scipy's f64 transforms"""
     sfft = pytest.importorskip("scipy.fft")
-    n, batch = 1 << lg, 3
+    n, batch = (1 << lg) + {"dct1": 1, "dst1": -1}.get(typ, 0), 3       # dct1 / dst1: the extension 2(N -/+ 1) is the power of two
     x = oracle.random_real_batch(n, batch, 0x7C00 + lg).reshape(-1)
     opts = {"type": typ, "shape": [n], "batch": batch, "direction": "forward", "normalize": "none", "layout": {"interleavedComplex": False}}
     got, (route, _) = run_plan(fft, dev, opts, x, x.size)
@@ -665,8 +665,9 @@ def test_dct_dst_real_fft_route_long(fft, dev, oracle, monkeypatch, typ, lg):
     old, (route0, _) = run_plan(fft, dev, opts, x, x.size)
     assert "trig-real" not in route0, route0
     xs = x.reshape(batch, n).astype(np.float64)
-    ref = {"dct2": lambda v: sfft.dct(v, type=2) / 2, "dct3": lambda v: sfft.dct(v, type=3) / 2,
-           "dst2": lambda v: sfft.dst(v, type=2) / 2, "dst3": lambda v: sfft.dst(v, type=3) / 2}[typ](xs).reshape(-1)
+    ref = {"dct2": lambda v: sfft.dct(v, type=2) / 2, "dct3": lambda v: sfft.dct(v, type=3) / 2, "dct4": lambda v: sfft.dct(v, type=4) / 2,
+           "dst2": lambda v: sfft.dst(v, type=2) / 2, "dst3": lambda v: sfft.dst(v, type=3) / 2, "dst4": lambda v: sfft.dst(v, type=4) / 2,
+           "dct1": lambda v: sfft.dct(v, type=1), "dst1": lambda v: sfft.dst(v, type=1) / 2}[typ](xs).reshape(-1)
     rms = float(np.sqrt(np.mean(ref ** 2)))
     assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= 2e-5 * rms * 8, (typ, lg, route)
     assert float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2))) <= 1e-6 * rms, (typ, lg, route)

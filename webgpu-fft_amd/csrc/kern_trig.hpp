@@ -92,42 +92,69 @@ static __global__ void __launch_bounds__(256) trig_post_kernel(const TrigArgs a)
 // with a sign on the odd samples and reversed bins.  Four times less FFT work and a quarter of the intermediate bytes.
 //   kind 8 dct2 fwd, 9 dst2 fwd (pre: x -> y = v, real;  post: z = V packed [line][L = N/2+1] -> y)
 //   kind 10 dct2 inv, 11 dst2 inv (pre: x -> z = V packed;  post: x = v, real -> y)
+// dct4 / dst4 (kinds 12, 13; N even) through a COMPLEX FFT of length N/2:  t[m] = (x[2m] + i x[N-1-2m]) e^{-i pi (4m+1)/(4N)},
+//   T = FFT_{N/2}(t), y = T[k] e^{-i pi k/N}:  X[2k] = Re y, X[N-1-2k] = -Im y;   dst4(x)[k] = (-1)^k dct4(reversed x)[k].
+// dct1 / dst1 (kinds 14, 15): the even / odd extension of length M = 2(N-1) / 2(N+1) is REAL, so its spectrum comes from the
+//   r2c route (M/2+1 bins, exactly the N bins needed) instead of a complex FFT of length M.  a.S carries M for these two.
 static __global__ void __launch_bounds__(256) trig_real_pre_kernel(const TrigArgs a) {
-  const bool fwd = a.kind < 10, sine = a.kind & 1;
-  const long long per = fwd ? a.N : a.L, total = a.lines * per;
+  const int kind = a.kind;
+  const bool sine = kind & 1;
+  // elements written per line: v real [N] (8, 9) / [M] (14, 15); V packed [L] (10, 11); t complex [L = N/2] (12, 13)
+  const long long per = kind < 10 ? a.N : (kind >= 14 ? a.S : a.L), total = a.lines * per;
   const double inv2n = 1.0 / (2.0 * (double)a.N);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long G = g / per, m = g - G * per;
     const float* x = a.x + G * a.N;
-    if (fwd) {
+    if (kind < 10) {
       const long long n = m < a.N / 2 ? 2 * m : 2 * (a.N - 1 - m) + 1;
       const float v = x[n];
       a.y[g] = (sine && (n & 1)) ? -v : v;
-    } else {
+    } else if (kind < 12) {
       const float re = sine ? x[a.N - 1 - m] : x[m];
       const float im = m == 0 ? 0.0f : (sine ? x[m - 1] : x[a.N - m]);
       const cf w = trig_phase((double)m * inv2n);
       cf v; v.x = 0.5f * (re * w.x + im * w.y); v.y = 0.5f * (re * w.y - im * w.x);
       a.z[g] = v;
+    } else if (kind < 14) {
+      // t[m] = (x[2m] + i x[N-1-2m]) e^{-i pi (4m+1)/(4N)}; dst4 reads the line reversed
+      const float re = sine ? x[a.N - 1 - 2 * m] : x[2 * m], im = sine ? x[2 * m] : x[a.N - 1 - 2 * m];
+      const cf w = trig_phase(-(double)(4 * m + 1) * inv2n * 0.5);
+      cf v; v.x = re * w.x - im * w.y; v.y = re * w.y + im * w.x;
+      a.z[g] = v;
+    } else if (kind == 14) {
+      a.y[g] = x[m < a.N ? m : a.S - m];                      // even extension, M = 2(N-1)
+    } else {
+      a.y[g] = (m == 0 || m == a.N + 1) ? 0.0f : (m <= a.N ? x[m - 1] : -x[a.S - m - 1]);   // odd extension, M = 2(N+1)
     }
   }
 }
 
 static __global__ void __launch_bounds__(256) trig_real_post_kernel(const TrigArgs a) {
-  const bool fwd = a.kind < 10, sine = a.kind & 1;
-  const long long per = fwd ? a.L : a.N, total = a.lines * per;
+  const int kind = a.kind;
+  const bool sine = kind & 1;
+  const long long per = kind < 10 ? a.L : (kind == 12 || kind == 13 ? a.L : a.N), total = a.lines * per;
   const double inv2n = 1.0 / (2.0 * (double)a.N);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long G = g / per, m = g - G * per;
     float* y = a.y + G * a.N;
-    if (fwd) {
+    if (kind < 10) {
       const cf w = trig_phase(-(double)m * inv2n), v = a.z[g];
       const float re = (v.x * w.x - v.y * w.y) * a.scale, im = -(v.x * w.y + v.y * w.x) * a.scale;
       y[sine ? a.N - 1 - m : m] = re;
       if (m > 0 && 2 * m != a.N) y[sine ? m - 1 : a.N - m] = im;
-    } else {
+    } else if (kind < 12) {
       const float v = a.x[G * a.N + ((m & 1) ? a.N - 1 - (m >> 1) : (m >> 1))];
       y[m] = ((sine && (m & 1)) ? -v : v) * a.scale;
+    } else if (kind < 14) {
+      // y = T[m] e^{-i pi m/N}:  X[2m] = Re y,  X[N-1-2m] = -Im y;  dst4: X[k] *= (-1)^k  (N even: N-1-2m is odd)
+      const cf w = trig_phase(-(double)m * inv2n * 2.0), v = a.z[g];
+      const float re = (v.x * w.x - v.y * w.y) * a.scale, im = -(v.x * w.y + v.y * w.x) * a.scale;
+      y[2 * m] = re;
+      y[a.N - 1 - 2 * m] = sine ? -im : im;
+    } else if (kind == 14) {
+      y[m] = a.z[G * a.L + m].x * a.scale;
+    } else {
+      y[m] = -0.5f * a.z[G * a.L + m + 1].y * a.scale;
     }
   }
 }

@@ -1114,25 +1114,28 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     const int64_t N = d.shape[a], lines = d.batch * (n / N);
     const int64_t L = kind == 0 ? 2 * (N - 1) : (kind == 4 ? 2 * (N + 1) : 2 * N);
     const uint64_t mark = b.work_top;
-    if (b.opt.trig_real && !b.opt.force_generic && S == 1 && N % 2 == 0 && N >= 4 && (kind == 1 || kind == 2 || kind == 5 || kind == 6)) {
-      // dense even lines: real FFT of length N behind Makhoul's permutation (kern_trig.hpp kinds 8..11)
-      const bool tfwd = kind == 1 || kind == 5;
-      const int rkind = (tfwd ? 8 : 10) + (kind >= 5 ? 1 : 0);
-      const int64_t P = N / 2 + 1;
-      const PtrRef v = b.alloc_work((uint64_t)lines * N * 4), V = b.alloc_work((uint64_t)lines * P * 8);
+    if (b.opt.trig_real && !b.opt.force_generic && S == 1 && N >= 4 && (N % 2 == 0 || kind == 0 || kind == 4)) {
+      // dense lines: a real FFT of length N behind Makhoul's permutation (dct2/dst2 and their inverses), a complex FFT of
+      // length N/2 (dct4/dst4), or the r2c of the real even/odd extension (dct1/dst1) -- kern_trig.hpp kinds 8..15
+      const bool tfwd = kind == 1 || kind == 5, tinv = kind == 2 || kind == 6, quarter = kind == 3 || kind == 7;
+      const int rkind = tfwd ? (kind == 1 ? 8 : 9) : tinv ? (kind == 2 ? 10 : 11) : quarter ? (kind == 3 ? 12 : 13) : (kind == 0 ? 14 : 15);
+      const int64_t M = quarter ? N / 2 : (kind == 0 || kind == 4 ? L : N);     // length of the FFT in the middle
+      const int64_t P = quarter ? M : M / 2 + 1;                                  // complex elements per line
+      const PtrRef v = quarter ? PtrRef() : b.alloc_work((uint64_t)lines * M * 4), V = b.alloc_work((uint64_t)lines * P * 8);
       const float last = a == rank - 1 ? scale : 1.0f;
       Step& pre = b.push(ST_TRIG_PRE);
-      pre.p[0] = cur; pre.p[1] = V; pre.p[2] = v;
-      pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = 1; pre.i[4] = rkind;
-      pre.grid = b.generic_grid(lines * (tfwd ? N : P));
+      pre.p[0] = cur; pre.p[1] = V; pre.p[2] = quarter ? dst : v;
+      pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = M; pre.i[4] = rkind;
+      pre.grid = b.generic_grid(lines * (tinv || quarter ? P : M));
       b.ir.route += "trig-real[kind=" + std::to_string(kind) + "] ";
-      const int rc = tfwd ? b.emit_r2c_even(v, V, N, lines, 1.0f, err) : b.emit_c2r_even(V, v, N, lines, 1.0f, err);
+      const int rc = quarter ? b.emit_axis(V, V, M, 1, lines, false, 1.0f, err)
+                   : tinv ? b.emit_c2r_even(V, v, M, lines, 1.0f, err) : b.emit_r2c_even(v, V, M, lines, 1.0f, err);
       if (rc) return rc;
       Step& post = b.push(ST_TRIG_POST);
-      post.p[0] = v; post.p[1] = V; post.p[2] = dst;
-      post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = 1; post.i[4] = rkind;
+      post.p[0] = quarter ? cur : v; post.p[1] = V; post.p[2] = dst;
+      post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = M; post.i[4] = rkind;
       post.f[0] = last;
-      post.grid = b.generic_grid(lines * (tfwd ? P : N));
+      post.grid = b.generic_grid(lines * (tfwd || quarter ? P : N));
       b.work_top = mark;
       cur = dst;
       S *= N;
