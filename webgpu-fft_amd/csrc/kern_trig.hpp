@@ -100,15 +100,19 @@ static __global__ void __launch_bounds__(256) trig_real_pre_kernel(const TrigArg
   const int kind = a.kind;
   const bool sine = kind & 1;
   // elements written per line: v real [N] (8, 9) / [M] (14, 15); V packed [L] (10, 11); t complex [L = N/2] (12, 13)
-  const long long per = kind < 10 ? a.N : (kind >= 14 ? a.S : a.L), total = a.lines * per;
+  // work items per line: sample pairs (8, 9: N/2; 12, 13: pairs of t, ceil(N/4)) so that every load is a float2 of adjacent
+  // samples and no line of x is fetched twice; one element of the extension / of V otherwise
+  const long long H = a.N / 2;
+  const long long per = kind < 10 ? H : (kind >= 14 ? a.S : (kind >= 12 ? (H + 1) / 2 : a.L)), total = a.lines * per;
   const double inv2n = 1.0 / (2.0 * (double)a.N);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long G = g / per, m = g - G * per;
     const float* x = a.x + G * a.N;
     if (kind < 10) {
-      const long long n = m < a.N / 2 ? 2 * m : 2 * (a.N - 1 - m) + 1;
-      const float v = x[n];
-      a.y[g] = (sine && (n & 1)) ? -v : v;
+      const cf p = *reinterpret_cast<const cf*>(x + 2 * m);      // N even, buffer offsets multiples of 8 bytes
+      float* v = a.y + G * a.N;
+      v[m] = p.x;
+      v[a.N - 1 - m] = sine ? -p.y : p.y;
     } else if (kind < 12) {
       const float re = sine ? x[a.N - 1 - m] : x[m];
       const float im = m == 0 ? 0.0f : (sine ? x[m - 1] : x[a.N - m]);
@@ -116,11 +120,23 @@ static __global__ void __launch_bounds__(256) trig_real_pre_kernel(const TrigArg
       cf v; v.x = 0.5f * (re * w.x + im * w.y); v.y = 0.5f * (re * w.y - im * w.x);
       a.z[g] = v;
     } else if (kind < 14) {
-      // t[m] = (x[2m] + i x[N-1-2m]) e^{-i pi (4m+1)/(4N)}; dst4 reads the line reversed
-      const float re = sine ? x[a.N - 1 - 2 * m] : x[2 * m], im = sine ? x[2 * m] : x[a.N - 1 - 2 * m];
-      const cf w = trig_phase(-(double)(4 * m + 1) * inv2n * 0.5);
-      cf v; v.x = re * w.x - im * w.y; v.y = re * w.y + im * w.x;
-      a.z[g] = v;
+      // t[m] = (x[2m] + i x[N-1-2m]) e^{-i pi (4m+1)/(4N)}; dst4 reads the line reversed.  One item forms t[m] and t[H-1-m]
+      // from the sample pairs (x[2m], x[2m+1]) and (x[N-2-2m], x[N-1-2m]).
+      const long long m2 = H - 1 - m;
+      const cf p = *reinterpret_cast<const cf*>(x + 2 * m), q = *reinterpret_cast<const cf*>(x + 2 * m2);
+      cf* t = a.z + G * a.L;
+      {
+        const float re = sine ? q.y : p.x, im = sine ? p.x : q.y;
+        const cf w = trig_phase(-(double)(4 * m + 1) * inv2n * 0.5);
+        cf v; v.x = re * w.x - im * w.y; v.y = re * w.y + im * w.x;
+        t[m] = v;
+      }
+      if (m2 != m) {
+        const float re = sine ? p.y : q.x, im = sine ? q.x : p.y;
+        const cf w = trig_phase(-(double)(4 * m2 + 1) * inv2n * 0.5);
+        cf v; v.x = re * w.x - im * w.y; v.y = re * w.y + im * w.x;
+        t[m2] = v;
+      }
     } else if (kind == 14) {
       a.y[g] = x[m < a.N ? m : a.S - m];                      // even extension, M = 2(N-1)
     } else {
@@ -132,7 +148,8 @@ static __global__ void __launch_bounds__(256) trig_real_pre_kernel(const TrigArg
 static __global__ void __launch_bounds__(256) trig_real_post_kernel(const TrigArgs a) {
   const int kind = a.kind;
   const bool sine = kind & 1;
-  const long long per = kind < 10 ? a.L : (kind == 12 || kind == 13 ? a.L : a.N), total = a.lines * per;
+  const long long H = a.N / 2;
+  const long long per = kind < 10 ? a.L : (kind < 12 ? H : (kind < 14 ? (H + 1) / 2 : a.N)), total = a.lines * per;   // 10..13: float2 stores
   const double inv2n = 1.0 / (2.0 * (double)a.N);
   for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
     const long long G = g / per, m = g - G * per;
@@ -143,14 +160,23 @@ static __global__ void __launch_bounds__(256) trig_real_post_kernel(const TrigAr
       y[sine ? a.N - 1 - m : m] = re;
       if (m > 0 && 2 * m != a.N) y[sine ? m - 1 : a.N - m] = im;
     } else if (kind < 12) {
-      const float v = a.x[G * a.N + ((m & 1) ? a.N - 1 - (m >> 1) : (m >> 1))];
-      y[m] = ((sine && (m & 1)) ? -v : v) * a.scale;
+      const float* v = a.x + G * a.N;
+      cf p; p.x = v[m] * a.scale; p.y = (sine ? -v[a.N - 1 - m] : v[a.N - 1 - m]) * a.scale;
+      *reinterpret_cast<cf*>(y + 2 * m) = p;
     } else if (kind < 14) {
       // y = T[m] e^{-i pi m/N}:  X[2m] = Re y,  X[N-1-2m] = -Im y;  dst4: X[k] *= (-1)^k  (N even: N-1-2m is odd)
-      const cf w = trig_phase(-(double)m * inv2n * 2.0), v = a.z[g];
+      // one item: bins m and H-1-m -> the sample pairs (X[2m], X[2m+1] = X[N-1-2(H-1-m)]) and (X[N-2-2m], X[N-1-2m])
+      const long long m2 = H - 1 - m;
+      const cf* T = a.z + G * a.L;
+      const cf w = trig_phase(-(double)m * inv2n * 2.0), v = T[m];
+      const cf w2 = trig_phase(-(double)m2 * inv2n * 2.0), v2 = T[m2];
       const float re = (v.x * w.x - v.y * w.y) * a.scale, im = -(v.x * w.y + v.y * w.x) * a.scale;
-      y[2 * m] = re;
-      y[a.N - 1 - 2 * m] = sine ? -im : im;
+      const float re2 = (v2.x * w2.x - v2.y * w2.y) * a.scale, im2 = -(v2.x * w2.y + v2.y * w2.x) * a.scale;
+      cf p, q;
+      p.x = re;  p.y = sine ? -im2 : im2;
+      q.x = re2; q.y = sine ? -im : im;
+      *reinterpret_cast<cf*>(y + 2 * m) = p;
+      if (m2 != m) *reinterpret_cast<cf*>(y + 2 * m2) = q;
     } else if (kind == 14) {
       y[m] = a.z[G * a.L + m].x * a.scale;
     } else {
