@@ -161,7 +161,7 @@ def main():
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
-        nd = re.fullmatch(r"(c2c|r2c)_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
+        nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
         if nd:
             ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
             tot = 1
@@ -185,7 +185,8 @@ def main():
     elif typ[:3] in ("dct", "dst"):   # real-to-real probe
         in_bytes = out_bytes = n * batch * 4
         in_row_floats = n
-        opts = {"type": typ, "shape": [n], "batch": batch, "direction": "forward", "normalize": "none", "layout": {"interleavedComplex": False}}
+        opts = {"type": typ, "shape": list(ND_SHAPE) if ND_SHAPE else [n], "batch": batch, "direction": "forward", "normalize": "none",
+                "layout": {"interleavedComplex": False}}
     elif typ == "r2c":
         shp = list(ND_SHAPE) if ND_SHAPE else [n]
         packed = (shp[0] // 2 + 1) * (n // shp[0])

@@ -73,6 +73,22 @@ def test_trig_nd(oracle, typ):
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), (typ, direction, route)
 
 
+@pytest.mark.parametrize("typ", TYPES)
+@pytest.mark.parametrize("shape", [[40, 36], [6, 70, 4], [33, 6, 8]])
+def test_trig_nd_strided_axes(oracle, typ, shape):
+    """axes >= 1 (stride > 1) of an N-D real array on the shortened routes: the tiled permutation / phase passes
+    (trig_real_*_tiled_kernel, ragged 32 x 32 tiles) around the dense FFTs; odd lengths fall back to the general route per axis"""
+    batch = 2
+    n = int(np.prod(shape))
+    x = oracle.random_real_batch(n, batch, 0x7AA0 + n).reshape(-1)
+    for direction in ("forward", "inverse"):
+        desc, _ = _desc({"type": typ, "shape": shape, "batch": batch, "direction": direction, "normalize": "unitary", "layout": {"interleavedComplex": False}})
+        got, route, _ = emu.run_plan(desc, x, x.size)
+        assert route.count("trig-real[") >= 2, route
+        want = oracle.trig_ref_batch(x, shape, batch, typ, direction, "unitary")
+        assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), (typ, direction, route)
+
+
 def test_trig_round_trips(oracle):
     """dct2 -> dct3 and dst2 -> dst3 invert each other up to 2/N; dct4 / dst4 are their own inverses up to 2/N"""
     n, batch = 32, 2

@@ -674,6 +674,38 @@ def test_dct_dst_real_fft_route_long(fft, dev, oracle, monkeypatch, typ, lg):
     assert float(np.max(np.abs(got.astype(np.float64) - old.astype(np.float64)))) <= 2e-5 * rms * 8, (typ, lg, route, route0)
 
 
+@pytest.mark.parametrize("typ", ["dct1", "dct2", "dct3", "dct4", "dst1", "dst2", "dst3", "dst4"])
+def test_dct_dst_nd_strided_axes(fft, dev, oracle, monkeypatch, typ):
+    """N-D real-to-real transforms: axes >= 1 go through the tiled permutation / phase passes (kern_trig.hpp) around dense FFTs.
+    Small arrays against the oracle; 1024 x 512 against scipy's f64 dctn / dstn and against the general route"""
+    sfft = pytest.importorskip("scipy.fft")
+    for shape, batch in (([40, 36], 2), ([6, 70, 4], 2)):
+        n = int(np.prod(shape))
+        x = oracle.random_real_batch(n, batch, 0x7D00 + n).reshape(-1)
+        opts = {"type": typ, "shape": shape, "batch": batch, "direction": "forward", "normalize": "backward", "layout": {"interleavedComplex": False}}
+        got, (route, _) = run_plan(fft, dev, opts, x, x.size)
+        assert route.count("trig-real[") >= 2, route
+        want = oracle.trig_ref_batch(x, shape, batch, typ, "forward", "backward")
+        assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), (typ, shape, route)
+    shape, batch = [1024, 512], 3
+    n = shape[0] * shape[1]
+    x = oracle.random_real_batch(n, batch, 0x7D77).reshape(-1)
+    opts = {"type": typ, "shape": shape, "batch": batch, "direction": "forward", "normalize": "none", "layout": {"interleavedComplex": False}}
+    got, (route, _) = run_plan(fft, dev, opts, x, x.size)
+    assert route.count("trig-real[") == 2, route
+    monkeypatch.setenv("MI355FFT_TRIG_REAL", "0")
+    old, (route0, _) = run_plan(fft, dev, opts, x, x.size)
+    assert "trig-real" not in route0, route0
+    xs = x.reshape(batch, shape[1], shape[0]).astype(np.float64)
+    k = int(typ[3])
+    f = sfft.dctn if typ.startswith("dct") else sfft.dstn
+    ref = (f(xs, type=k, axes=(1, 2)) / (1.0 if typ == "dct1" else 4.0)).reshape(-1)
+    rms = float(np.sqrt(np.mean(ref ** 2)))
+    assert float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2))) <= 1e-6 * rms, (typ, route)
+    assert float(np.max(np.abs(got.astype(np.float64) - ref))) <= 2e-4 * rms, (typ, route)
+    assert float(np.max(np.abs(got.astype(np.float64) - old.astype(np.float64)))) <= 2e-4 * rms, (typ, route, route0)
+
+
 def test_torch_fft_cross_check(fft, dev, oracle):
     """independent f32 FFT (torch.fft on the same GPU) agrees to f32 rounding — not the parity oracle"""
     torch = pytest.importorskip("torch")

@@ -201,8 +201,10 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
     case ST_TRIG_POST: {
       TrigArgs a{};
       a.x = (const float*)ptr[0]; a.z = (cf*)ptr[1]; a.y = (float*)ptr[2];
-      a.lines = s.i[0]; a.N = s.i[1]; a.L = s.i[2]; a.S = s.i[3]; a.kind = (int)s.i[4]; a.scale = s.f[0];
-      if (a.kind >= 8) {
+      a.lines = s.i[0]; a.N = s.i[1]; a.L = s.i[2]; a.S = s.i[3]; a.kind = (int)s.i[4]; a.scale = s.f[0]; a.stride = s.i[5] ? s.i[5] : 1;
+      if (a.kind >= 8 && a.stride > 1) {
+        if (s.kind == ST_TRIG_PRE) l.launch(trig_real_pre_tiled_kernel, s.grid, 256u, 0u, a); else l.launch(trig_real_post_tiled_kernel, s.grid, 256u, 0u, a);
+      } else if (a.kind >= 8) {
         if (s.kind == ST_TRIG_PRE) l.launch(trig_real_pre_kernel, s.grid, 256u, 0u, a); else l.launch(trig_real_post_kernel, s.grid, 256u, 0u, a);
       } else if (s.kind == ST_TRIG_PRE) l.launch(trig_pre_kernel, s.grid, 256u, 0u, a); else l.launch(trig_post_kernel, s.grid, 256u, 0u, a);
       return true;

@@ -29,6 +29,7 @@ struct TrigArgs {
   long long lines, N, L, S;
   int kind;
   float scale;        // post only
+  long long stride;   // kinds >= 8: element stride of the axis (1: the dense kernels; > 1: the tiled ones)
 };
 
 MI_DEV cf trig_phase(double turns_half) {   // e^{i pi t}
@@ -182,6 +183,133 @@ static __global__ void __launch_bounds__(256) trig_real_post_kernel(const TrigAr
     } else {
       y[m] = -0.5f * a.z[G * a.L + m + 1].y * a.scale;
     }
+  }
+}
+
+// ---- kinds 8..15 along a strided axis (S > 1: axes >= 1 of an N-D real array) ----
+// Array side: sample n of line G = o*S + inner sits at o*S*N + inner + n*S, so adjacent LINES are adjacent floats; dense side:
+// element e of line G at G*pitch + e.  32 x 32 tiles through LDS turn one walk into the other (array side along `inner`, dense
+// side along e) so both sides move whole cache lines.  Same arithmetic as the dense kernels, one dense element per item.
+MI_DEV cf trig_tile_pre_value(int kind, const float* xb, long long S, long long N, long long M, long long e) {
+  const bool sine = kind & 1;
+  const double inv2n = 1.0 / (2.0 * (double)N);
+  const auto X = [&](long long n) { return xb[n * S]; };
+  cf v; v.x = 0.0f; v.y = 0.0f;
+  if (kind < 10) {
+    const long long n = e < N / 2 ? 2 * e : 2 * (N - 1 - e) + 1;
+    v.x = (sine && (n & 1)) ? -X(n) : X(n);
+  } else if (kind < 12) {
+    const float re = sine ? X(N - 1 - e) : X(e);
+    const float im = e == 0 ? 0.0f : (sine ? X(e - 1) : X(N - e));
+    const cf w = trig_phase((double)e * inv2n);
+    v.x = 0.5f * (re * w.x + im * w.y); v.y = 0.5f * (re * w.y - im * w.x);
+  } else if (kind < 14) {
+    const float re = sine ? X(N - 1 - 2 * e) : X(2 * e), im = sine ? X(2 * e) : X(N - 1 - 2 * e);
+    const cf w = trig_phase(-(double)(4 * e + 1) * inv2n * 0.5);
+    v.x = re * w.x - im * w.y; v.y = re * w.y + im * w.x;
+  } else if (kind == 14) {
+    v.x = X(e < N ? e : M - e);
+  } else {
+    v.x = (e == 0 || e == N + 1) ? 0.0f : (e <= N ? X(e - 1) : -X(M - e - 1));
+  }
+  return v;
+}
+
+static __global__ void __launch_bounds__(256) trig_real_pre_tiled_kernel(const TrigArgs a) {
+  MI_SMEM_DECL_STATIC(cf, tile, 32 * 33);
+  const int kind = a.kind;
+  const bool dense_real = kind < 10 || kind >= 14;
+  const long long S = a.stride, M = a.S, outer = a.lines / S;
+  const long long per = kind < 10 ? a.N : (kind >= 14 ? M : a.L);          // dense elements per line
+  const long long pitch = dense_real ? per : a.L;
+  const long long te_n = (per + 31) / 32, ti_n = (S + 31) / 32, tiles = outer * ti_n * te_n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long long te = t % te_n, r0 = t / te_n, ti = r0 % ti_n, o = r0 / ti_n;
+    {
+      const long long inner = ti * 32 + tx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long e = te * 32 + ty + 8 * r;
+        if (inner < S && e < per) tile[(ty + 8 * r) * 33 + tx] = trig_tile_pre_value(kind, a.x + o * S * a.N + inner, S, a.N, M, e);
+      }
+    }
+    __syncthreads();
+    {
+      const long long e = te * 32 + tx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long inner = ti * 32 + ty + 8 * r;
+        if (inner < S && e < per) {
+          const cf v = tile[tx * 33 + ty + 8 * r];
+          const long long G = o * S + inner;
+          if (dense_real) a.y[G * pitch + e] = v.x; else a.z[G * pitch + e] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static __global__ void __launch_bounds__(256) trig_real_post_tiled_kernel(const TrigArgs a) {
+  MI_SMEM_DECL_STATIC(cf, tile, 32 * 33);
+  const int kind = a.kind;
+  const bool sine = kind & 1;
+  const long long S = a.stride, N = a.N, outer = a.lines / S;
+  const long long per = kind < 10 ? a.L : (kind == 12 || kind == 13 ? a.L : N);   // dense elements walked per line
+  const double inv2n = 1.0 / (2.0 * (double)N);
+  const long long te_n = (per + 31) / 32, ti_n = (S + 31) / 32, tiles = outer * ti_n * te_n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const long long te = t % te_n, r0 = t / te_n, ti = r0 % ti_n, o = r0 / ti_n;
+    {
+      const long long e = te * 32 + tx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long inner = ti * 32 + ty + 8 * r;
+        if (inner >= S || e >= per) continue;
+        const long long G = o * S + inner;
+        cf out; out.x = 0.0f; out.y = 0.0f;
+        if (kind < 10) {
+          const cf w = trig_phase(-(double)e * inv2n), v = a.z[G * a.L + e];
+          out.x = (v.x * w.x - v.y * w.y) * a.scale; out.y = -(v.x * w.y + v.y * w.x) * a.scale;
+        } else if (kind < 12) {
+          const float v = a.x[G * N + ((e & 1) ? N - 1 - (e >> 1) : (e >> 1))];
+          out.x = ((sine && (e & 1)) ? -v : v) * a.scale;
+        } else if (kind < 14) {
+          const cf w = trig_phase(-(double)e * inv2n * 2.0), v = a.z[G * a.L + e];
+          out.x = (v.x * w.x - v.y * w.y) * a.scale;
+          const float im = -(v.x * w.y + v.y * w.x) * a.scale;
+          out.y = sine ? -im : im;
+        } else if (kind == 14) {
+          out.x = a.z[G * a.L + e].x * a.scale;
+        } else {
+          out.x = -0.5f * a.z[G * a.L + e + 1].y * a.scale;
+        }
+        tile[tx * 33 + ty + 8 * r] = out;
+      }
+    }
+    __syncthreads();
+    {
+      const long long inner = ti * 32 + tx;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long e = te * 32 + ty + 8 * r;
+        if (inner >= S || e >= per) continue;
+        const cf v = tile[(ty + 8 * r) * 33 + tx];
+        float* y = a.y + o * S * N + inner;
+        if (kind < 10) {
+          y[(sine ? N - 1 - e : e) * S] = v.x;
+          if (e > 0 && 2 * e != N) y[(sine ? e - 1 : N - e) * S] = v.y;
+        } else if (kind == 12 || kind == 13) {
+          y[2 * e * S] = v.x;
+          y[(N - 1 - 2 * e) * S] = v.y;
+        } else {
+          y[e * S] = v.x;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 

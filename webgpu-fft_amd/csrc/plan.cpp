@@ -1114,7 +1114,7 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     const int64_t N = d.shape[a], lines = d.batch * (n / N);
     const int64_t L = kind == 0 ? 2 * (N - 1) : (kind == 4 ? 2 * (N + 1) : 2 * N);
     const uint64_t mark = b.work_top;
-    if (b.opt.trig_real && !b.opt.force_generic && S == 1 && N >= 4 && (N % 2 == 0 || kind == 0 || kind == 4)) {
+    if (b.opt.trig_real && !b.opt.force_generic && N >= 4 && (N % 2 == 0 || kind == 0 || kind == 4)) {
       // dense lines: a real FFT of length N behind Makhoul's permutation (dct2/dst2 and their inverses), a complex FFT of
       // length N/2 (dct4/dst4), or the r2c of the real even/odd extension (dct1/dst1) -- kern_trig.hpp kinds 8..15
       const bool tfwd = kind == 1 || kind == 5, tinv = kind == 2 || kind == 6, quarter = kind == 3 || kind == 7;
@@ -1125,17 +1125,19 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       const float last = a == rank - 1 ? scale : 1.0f;
       Step& pre = b.push(ST_TRIG_PRE);
       pre.p[0] = cur; pre.p[1] = V; pre.p[2] = quarter ? dst : v;
-      pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = M; pre.i[4] = rkind;
-      pre.grid = b.generic_grid(lines * (tinv || quarter ? P : M));
+      pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = M; pre.i[4] = rkind; pre.i[5] = S;
+      // S > 1 (axes >= 1): 32 x 32 tiles through LDS, one workgroup per tile
+      const auto tiled_grid = [&](int64_t per) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((lines / S) * ((S + 31) / 32) * ((per + 31) / 32), (int64_t)b.opt.compute_units * 16)); };
+      pre.grid = S > 1 ? tiled_grid(tinv || quarter ? P : M) : b.generic_grid(lines * (tinv || quarter ? P : M));
       b.ir.route += "trig-real[kind=" + std::to_string(kind) + "] ";
       const int rc = quarter ? b.emit_axis(V, V, M, 1, lines, false, 1.0f, err)
                    : tinv ? b.emit_c2r_even(V, v, M, lines, 1.0f, err) : b.emit_r2c_even(v, V, M, lines, 1.0f, err);
       if (rc) return rc;
       Step& post = b.push(ST_TRIG_POST);
       post.p[0] = quarter ? cur : v; post.p[1] = V; post.p[2] = dst;
-      post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = M; post.i[4] = rkind;
+      post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = M; post.i[4] = rkind; post.i[5] = S;
       post.f[0] = last;
-      post.grid = b.generic_grid(lines * (tfwd || quarter ? P : N));
+      post.grid = S > 1 ? tiled_grid(tfwd || quarter ? P : N) : b.generic_grid(lines * (tfwd || quarter ? P : N));
       b.work_top = mark;
       cur = dst;
       S *= N;
