@@ -160,7 +160,7 @@ def main():
 
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
-        m = re.fullmatch(r"(c2c|r2c|c2r|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
+        m = re.fullmatch(r"(c2c|r2c|c2r|fftconv|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
         nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
         if nd:
             ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
@@ -171,7 +171,7 @@ def main():
                                         f"{len(ND_SHAPE)}-D {nd.group(1)} {nd.group(2)} batch={nd.group(3)} (probe; NOT a BASELINE config)")
         elif m:
             nn = 1 << int(m.group(3)) if m.group(2) == "2p" else int(m.group(3))
-            WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) == "c2c" else 8,
+            WORKLOADS[args.workload] = (m.group(1), nn, int(m.group(4)), 16 if m.group(1) in ("c2c", "fftconv") else 8,
                                         f"1D {m.group(1)} N={nn} batch={m.group(4)} (probe; NOT a BASELINE config)")
         else:
             raise SystemExit(f"unknown workload {args.workload}")
@@ -182,6 +182,10 @@ def main():
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n
         opts = {"type": "c2c", "shape": list(ND_SHAPE) if ND_SHAPE else [n], "batch": batch, "direction": "forward", "normalize": "none"}
+    elif typ == "fftconv":   # circular convolution with one full-length kernel (probe): forward FFTs, product, inverse FFT
+        in_bytes = out_bytes = n * batch * 8
+        in_row_floats = 2 * n
+        opts = {"type": "fftconv", "shape": [n], "batch": batch, "fftConv": {"mode": "convolution", "boundary": "circular", "kernelCount": 1}}
     elif typ[:3] in ("dct", "dst"):   # real-to-real probe
         in_bytes = out_bytes = n * batch * 4
         in_row_floats = n
@@ -210,7 +214,12 @@ def main():
     plan = mi355fft.createPlan(dev, opts)
     route, launches = plan.describe()
     enc = dev.createCommandEncoder()
-    plan.exec(enc, {"input": inp, "output": out})
+    exec_args = {"input": inp, "output": out}
+    if typ == "fftconv":
+        kbuf = dev.createBuffer({"size": n * 8})
+        dev.fillRandom(kbuf, 0, 2 * n, 1, 0x5EED0004, 0)
+        exec_args["kernel"] = kbuf
+    plan.exec(enc, exec_args)
     cmds = enc.finish()
     ev = HipEvents()
     e0, e1 = ev.create(), ev.create()
