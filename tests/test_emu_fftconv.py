@@ -199,3 +199,41 @@ def test_fftconv_zero_pad(oracle, shape, kshape, boundary, zero_pad):
     assert ("zero-read" in route) == bool(zr) and ("zero-write" in route) == bool(zw), route
     _close(got, want.reshape(-1), 4e-3, 4e-3, f"fftconv zeroPad {shape} {boundary}")
     assert oracle.rel_l2(got, want.reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("shape,ks,boundary,mode,K", [([8192], None, "circular", "convolution", 2), ([8192], [100], "circular", "correlation", 1),
+                                                       ([100], [29], "linear-full", "convolution", 3), ([1000], [25], "linear-same", "correlation", 2),
+                                                       ([4000], [97], "linear-valid", "convolution", 1)])
+def test_fftconv_product_fused_into_forward_lines(oracle, monkeypatch, shape, ks, boundary, mode, K):
+    """1-D, power-of-two FFT length: kernel-spectrum product behind the forward line FFT's last stage (fft_lines_mul_kernel), one
+    launch per kernel; against the oracle's fftConvRef restatement and against the forward + pointwise route"""
+    batch = 5 if shape[0] < 8192 else 2
+    n, kn = shape[0], (ks or shape)[0]
+    x = oracle.random_complex_interleaved(n * batch, 0xC0DE + n)
+    kern = oracle.random_complex_interleaved(kn * K, 0xC1DE + kn)
+    desc, _ = _desc({"type": "fftconv", "shape": shape, "batch": batch,
+                     "fftConv": {"mode": mode, "boundary": boundary, "kernelCount": K, "kernelShape": ks}})
+    want = np.concatenate([oracle.fftconv_ref(x, kern[2 * k * kn:2 * (k + 1) * kn], shape, batch, mode, boundary, ks)[0] for k in range(K)])
+    got, route, _ = emu.run_plan(desc, x, want.size, kernel=kern)
+    assert "lines-mul[" in route, route
+    _close(got, want, 4e-3, 4e-3, route)
+    assert oracle.rel_l2(got, want) < 1e-5, route
+    monkeypatch.setenv("MI355_EMU_CONV_LINES", "0")
+    old, route0, _ = emu.run_plan(desc, x, want.size, kernel=kern)
+    assert "lines-mul[" not in route0, route0
+    assert oracle.rel_l2(got, old) < 1e-6
+
+
+def test_fftconv_fused_route_gives_way_to_line_kernels_at_throughput_sizes(oracle, monkeypatch):
+    """the one-launch fftconv kernel is the latency route; above conv_fused_max_points the forward-mul + inverse line launches take
+    over (same results)"""
+    shape, batch, K = [256], 6, 2
+    x = oracle.random_complex_interleaved(256 * batch, 0xC2DE)
+    kern = oracle.random_complex_interleaved(256 * K, 0xC3DE)
+    desc, _ = _desc({"type": "fftconv", "shape": shape, "batch": batch, "fftConv": {"mode": "convolution", "boundary": "circular", "kernelCount": K}})
+    a, route_a, launches_a = emu.run_plan(desc, x, 2 * 256 * batch * K, kernel=kern)
+    assert route_a.startswith("fftconv-fused[") and launches_a == 1, route_a
+    monkeypatch.setenv("MI355_EMU_CONV_FUSED_MAX_POINTS", "1024")
+    b, route_b, _ = emu.run_plan(desc, x, 2 * 256 * batch * K, kernel=kern)
+    assert "lines-mul[N=256]" in route_b and "fftconv-fused" not in route_b, route_b
+    assert oracle.rel_l2(a, b) < 1e-6

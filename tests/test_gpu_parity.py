@@ -474,6 +474,29 @@ def test_fftconv_golden_fixtures(fft, dev, oracle, manifest):
     assert ran >= 10
 
 
+@pytest.mark.parametrize("shape,ks,boundary,mode,K", [([8192], None, "circular", "convolution", 2), ([16384], [100], "circular", "correlation", 1),
+                                                       ([100], [29], "linear-full", "convolution", 3), ([1000], [25], "linear-same", "correlation", 2),
+                                                       ([4000], [97], "linear-valid", "convolution", 1)])
+def test_fftconv_product_fused_into_forward_lines(fft, dev, oracle, monkeypatch, shape, ks, boundary, mode, K):
+    """1-D, power-of-two FFT length: the kernel-spectrum product rides the forward line FFT (fft_lines_mul_kernel); against the
+    oracle's fftConvRef restatement and against the forward + pointwise route"""
+    batch = 3
+    n, kn = shape[0], (ks or shape)[0]
+    x = oracle.random_complex_interleaved(n * batch, 0xC0DE + n)
+    kern = oracle.random_complex_interleaved(kn * K, 0xC1DE + kn)
+    opts = {"type": "fftconv", "shape": shape, "batch": batch, "fftConv": {"mode": mode, "boundary": boundary, "kernelCount": K, "kernelShape": ks}}
+    want = np.concatenate([oracle.fftconv_ref(x, kern[2 * k * kn:2 * (k + 1) * kn], shape, batch, mode, boundary, ks)[0] for k in range(K)])
+    kernels = [kern[2 * k * kn:2 * (k + 1) * kn] for k in range(K)]
+    got, (route, _) = run_plan(fft, dev, opts, x, want.size, kernel=kernels)
+    assert "lines-mul[" in route, route
+    check(oracle, got, want, route, 4e-3, 4e-3)
+    assert oracle.rel_l2(got, want) < 1e-5, route
+    monkeypatch.setenv("MI355FFT_CONV_LINES", "0")
+    old, (route0, _) = run_plan(fft, dev, opts, x, want.size, kernel=kernels)
+    assert "lines-mul[" not in route0, route0
+    assert oracle.rel_l2(got, old) < 1e-6
+
+
 def test_fftconv_cfg4_channel_lane_preset(fft, dev, oracle, manifest):
     """BASELINE config 4 with sentinel preservation (mirror of complete.suite.js:4812-4830)"""
     cases, _ = manifest

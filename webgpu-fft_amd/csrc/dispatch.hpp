@@ -35,6 +35,10 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
           l.launch(fft_lines_r2c_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
         }                                                                                \
+        if (a.real_mode == 4) {                                                          \
+          l.launch(fft_lines_mul_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          return true;                                                                   \
+        }                                                                                \
       }                                                                                  \
       if constexpr (!(IC) && !(OC) && (SI) && (SO) && (TW) == 0) {                        \
         if (a.real_mode == 2) {                                                          \

@@ -70,7 +70,7 @@ struct LineArgs {
   float scale;
   int fs_shift;
   unsigned fs_lo_mask;
-  int real_mode;         // 1: fft_lines_r2c_kernel (real line read as complex pairs, split fused behind the last stage); 2: fft_lines_c2r_kernel
+  int real_mode;         // 4: fft_lines_mul_kernel (tw_lo = kernel spectrum, fs_shift != 0: conjugate it);  1: fft_lines_r2c_kernel (real line read as complex pairs, split fused behind the last stage); 2: fft_lines_c2r_kernel
   long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group); COL_RAGGED: tiles per group
 };
 
@@ -362,6 +362,48 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
       x[k] = xk;
       if (k == 0) x[H] = xm;
       else if (km != k) x[km] = xm;
+    }
+    __syncthreads();   // LDS is re-used by the next tile
+  }
+}
+
+// fftconv, first half (src/kernels/fft_conv.js:3-66 pointwise product): forward FFT of complex lines with the
+// finished lines KEPT in LDS, multiplied there by the kernel spectrum a.tw_lo[k] (its conjugate when a.fs_shift != 0: correlation)
+// and stored — the separate pointwise pass (8 B read + 8 B written per point) disappears.  One spectrum for every line.
+template <class C>
+__global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArgs a) {
+  static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_lds = lds + C::DATA_ELEMS;
+  const int t = threadIdx.x;
+  if constexpr (C::TW_LDS_ELEMS > 0) {
+    for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+    __syncthreads();
+  }
+  const float ksign = a.fs_shift ? -1.0f : 1.0f;
+  for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    cf v[C::E];
+    stage_read<C, 0>(v, a, tile, t, lds);
+    stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
+    __syncthreads();
+    stage_read<C, 1>(v, a, tile, t, lds);
+    __syncthreads();
+    stage_compute_write<C, 1, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+    if constexpr (C::NSTAGES == 3) {
+      __syncthreads();
+      stage_read<C, 2>(v, a, tile, t, lds);
+      __syncthreads();
+      stage_compute_write<C, 2, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+    }
+    __syncthreads();
+    const long long G0 = tile * C::T;
+    const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
+    for (int p = t; p < live * C::N; p += C::THREADS) {
+      const int line = p / C::N, k = p - line * C::N;
+      cf h = a.tw_lo[k];
+      h.y *= ksign;
+      a.out[(G0 + line) * a.out_outer_stride + k] = cmul(lds[lds_index<C>(line, k)], h) * a.scale;
     }
     __syncthreads();   // LDS is re-used by the next tile
   }

@@ -128,6 +128,8 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_C2R")) o.lines_c2r = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_TRIG_REAL")) o.trig_real = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_CONV_LINES")) o.conv_lines = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_CONV_FUSED_MAX_POINTS")) { const long long v = std::atoll(s); if (v >= 0) o.conv_fused_max_points = v; }
   if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
@@ -1206,7 +1208,10 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   } else b.ir.out_bytes = (uint64_t)K * B * oN * 8;
 
   // small 1-D circular problems: one launch, one workgroup per batch entry (kern_fftconv.hpp)
-  if (!b.opt.force_generic && !zpad && rank == 1 && d.conv_boundary == MI355FFT_CIRCULAR && K <= 15) {
+  // (throughput-sized problems do better on the line kernels below: measured 49 vs 150 GPoints/s at N=1024, batch 65536)
+  const bool lines_mul_ok = b.opt.conv_lines && is_pow2(fN) && fN >= 64 && fN <= b.opt.max_line;
+  if (!b.opt.force_generic && !zpad && rank == 1 && d.conv_boundary == MI355FFT_CIRCULAR && K <= 15 &&
+      !(lines_mul_ok && B * fN * K > b.opt.conv_fused_max_points)) {
     const ConvKernelMeta* cm = nullptr;
     for (const auto& m : conv_kernel_registry())
       if (m.N == fN && m.TL >= K + 1 && (!cm || m.TL < cm->TL)) cm = &m;
@@ -1253,17 +1258,39 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   else if (d.zero_read.enabled) { Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = xf; c.i[0] = B * fN * 8; }
   const bool staged = embed || d.input.strided || d.zero_read.enabled;
   if (d.zero_read.enabled) { emit_zero_outside(b, xf, d.zero_read, fs, rank, B); b.ir.route += "zero-read "; }
-  rc = b.emit_nd(staged ? xf : in, xf, fs, rank, B, false, 1.0f, err);
-  if (rc) return rc;
+  // 1-D, power-of-two FFT length with an LDS-resident line kernel: the product with kernel k's spectrum rides the forward FFT's
+  // last stage (kern_lines.hpp fft_lines_mul_kernel), one launch per kernel instead of forward FFT + K pointwise passes
+  const LineKernelMeta* mul_m = nullptr;
+  if (b.opt.conv_lines && !b.opt.force_generic && rank == 1 && is_pow2(fN) && fN <= b.opt.max_line && !(b.opt.xcd_fused == 2 && fN == 4096)) {
+    mul_m = find_line_kernel((int)fN, false, false, false, false, 0);
+    if (mul_m && (mul_m->lds_bytes == 0 || mul_m->R1 <= 1)) mul_m = nullptr;
+  }
+  if (!mul_m) {
+    rc = b.emit_nd(staged ? xf : in, xf, fs, rank, B, false, 1.0f, err);
+    if (rc) return rc;
+  }
+  const PtrRef mul_tables = mul_m ? b.line_tables(*mul_m) : PtrRef();
   // 3. per kernel: product, inverse transform scaled by 1/Nfft, crop + place
   PtrRef y = b.alloc_work((uint64_t)B * fN * 8);
   const float inv_n = (float)(1.0 / (double)fN);
   const bool direct_out = !embed && !d.output.strided;   // the inverse FFT can land in the output itself
   for (int64_t k = 0; k < K; ++k) {
-    Step& pm = b.push(ST_POINTWISE);
-    pm.p[0] = xf; pm.p[1] = y; pm.p[2] = kf.plus(k * fN * 8);
-    pm.i[0] = fN; pm.i[1] = B * fN; pm.i[2] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; pm.f[0] = 1.0f;
-    pm.grid = b.generic_grid(B * fN);
+    if (mul_m) {
+      Step& st = b.push(ST_LINES);
+      st.variant = mul_m->id;
+      st.p[0] = staged ? xf : in; st.p[1] = y; st.p[2] = mul_tables; st.p[3] = kf.plus(k * fN * 8);
+      const int64_t tiles = (B + mul_m->T - 1) / mul_m->T;
+      st.i[0] = tiles; st.i[1] = B; st.i[2] = 1; st.i[3] = fN; st.i[4] = 1; st.i[5] = fN;
+      st.i[6] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; st.i[9] = 4;
+      st.f[0] = 1.0f;
+      st.grid = b.lines_grid(*mul_m, tiles);
+      if (k == 0) b.ir.route += "lines-mul[N=" + std::to_string(fN) + "] ";
+    } else {
+      Step& pm = b.push(ST_POINTWISE);
+      pm.p[0] = xf; pm.p[1] = y; pm.p[2] = kf.plus(k * fN * 8);
+      pm.i[0] = fN; pm.i[1] = B * fN; pm.i[2] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; pm.f[0] = 1.0f;
+      pm.grid = b.generic_grid(B * fN);
+    }
     if (direct_out && d.conv_output_layout == MI355FFT_KERNEL_MAJOR) {
       rc = b.emit_nd(y, out.plus(k * B * oN * 8), fs, rank, B, true, inv_n, err);
       if (rc) return rc;
