@@ -118,7 +118,7 @@ struct PlannerOptions {
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
-  int64_t conv_fused_max_points = (int64_t)1 << 21;   // fftconv-fused (one launch, latency route) up to this many points B*N*K; above: forward-mul + inverse line launches
+  int64_t conv_fused_max_points = (int64_t)1 << 20;   // fftconv-fused (one launch, latency route) up to this many points B*N*K; above: forward-mul + inverse line launches
   int conv_lines = 1;                  // fftconv: kernel-spectrum product fused behind the forward line FFT (1-D, power-of-two FFT length <= max_line)
   int trig_real = 1;                   // dct2/dst2/dct3/dst3 along a dense even axis through a real FFT of length N (kern_trig.hpp)
   int lines_c2r = 1;                   // c2r twin (pair pre-split from global into LDS before the first stage): half lengths <= 8192
