@@ -14,6 +14,8 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -103,6 +105,58 @@ def cpu_baseline(n, seconds_target=12.0):
             "sample": f"{sample} transforms of N={n} x {rounds} rounds in {dt_total:.1f}s, oracle/oracle.c fft1d_ref (radix-2, f32 storage, f64 twiddles), {threads} pthreads"}
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_node(n, seconds_target=10.0):
+    """The reference's Node.js CPU correctness path (src/utils/math.js:25-88 fft1dRefInterleaved, single-threaded JS) as restated
+    in oracle/oracle.mjs (pinned bit-exact to reference-generated fixtures), timed on the host cores: one Node child process per
+    usable core (Node 12 here: child processes, no worker_threads needed), each transforming its own seeded slice of the
+    workload for ~seconds_target; value = total points / the longest child's time."""
+    import shutil
+    node = shutil.which("node")
+    if node is None:
+        raise RuntimeError("node not on PATH")
+    total, usable = os.cpu_count() or 1, _usable_cores()
+    used = max(1, min(usable, 64))
+    per = 1 if n >= (1 << 18) else max(1, (1 << 18) // n)       # transforms per child per round (~2^18 points)
+    worker = os.path.join(ROOT, "oracle", "cpu_baseline_worker.mjs")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([node, worker, str(n), str(per), str(0x5EED00C0 + i), str(seconds_target)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(used)]
+    pts, longest, version, rounds = 0.0, 0.0, None, 0
+    for p in procs:
+        so, se = p.communicate(timeout=seconds_target * 6 + 60)
+        if p.returncode != 0:
+            raise RuntimeError(f"node worker failed: {se.strip()[-200:]}")
+        d = json.loads(so.strip().splitlines()[-1])
+        pts += d["points"]
+        longest = max(longest, d["seconds"])
+        rounds += d["rounds"]
+        version = d["node"]
+    wall = time.perf_counter() - t0
+    value = pts / longest / 1e9
+    return {"value": value, "unit": "GPoints/s", "cores": used, "kind": "node", "node": version, "cpu_model": _cpu_model(),
+            "cores_total": total, "cores_used": used, "per_core": value / used,
+            "sample": f"{used} Node processes x {per} transform(s) of N={n} x {rounds} rounds in all, {longest:.1f}s each ({wall:.1f}s wall), "
+                      f"oracle/oracle.mjs fft1dRef = restatement of the reference's src/utils/math.js:25-88 (radix-2, Float32Array storage, f64 twiddle recurrence)"}
+
+
 def pmc_traffic(workload):
     """HBM bytes per step from the committed PMC passes (profiles/r*_pmc_traffic_<workload>.json), newest round"""
     import glob
@@ -138,6 +192,34 @@ def time_single_pass(mi355fft, dev, ev, opts, inp, out, which, reps):
     return ms * 1e3 / (reps * max(launches, 1)), launches
 
 
+def launch_ranks(n):
+    """parent side of `bench.py --gpus N`: torch.distributed.run with one rank per GPU on this node, as a child process"""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_worker(args):
+    """MI355FFT_BENCH_STUB=1: the rank plumbing of a bench run without a GPU (tests/test_bench_launcher.py)"""
+    from mi355fft.sharding import Group, rank_info, shard_range
+    rank, local_rank, world = rank_info()
+    group = Group("gloo")
+    seen = int(round(group.reduce_sum([1.0])[0]))
+    first, last = shard_range(rank, world, 4096 * world)
+    spans = group.reduce_sum([float(last - first)])
+    group.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": None, "n_gpus": world, "ranks_seen": seen, "collective_backend": group.backend or "none",
+                          "global_batch": int(spans[0]), "steps": args.steps, "warmup": args.warmup}), flush=True)
+    group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,15 +230,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU) before anything here has
+        # touched the GPU — this parent never imports torch or opens a device — and exit with the launcher's code.
+        sys.exit(launch_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if os.environ.get("MI355FFT_BENCH_STUB"):   # CPU-tier test of the launcher plumbing: no device work at all
+        return stub_worker(args)
+
     import torch  # first: its bundled HIP runtime is the one the library then binds to
     import mi355fft
     from mi355fft.sharding import Group, rank_info, shard_range
     rank, local_rank, world = rank_info()
-    if os.environ.get("MI355FFT_BENCH_SHARE_GPU"):   # rehearsal on a 1-GPU box: all ranks use device 0 (RCCL refuses, gloo takes over)
+    share_gpu = bool(os.environ.get("MI355FFT_BENCH_SHARE_GPU"))
+    if share_gpu:   # rehearsal on a 1-GPU box: all ranks use device 0 (RCCL refuses two ranks on one device, gloo takes over)
         local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-    group = Group("nccl", torch.device("cuda", local_rank))   # RCCL over xGMI; barrier + scalar reductions only
+    # RCCL over xGMI; barrier + scalar reductions only.  On a real multi-GPU run a failing nccl init is an error, not a fallback.
+    group = (Group("gloo") if share_gpu else Group("nccl", torch.device("cuda", local_rank)))
+    ranks_seen = int(round(group.reduce_sum([1.0])[0]))
+    if ranks_seen != world:
+        raise SystemExit(f"collective saw {ranks_seen} ranks, expected {world}")
 
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
@@ -282,6 +378,7 @@ def main():
             "value": value, "unit": "GPoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (device-side seeded PRNG twin of the oracle, uniform (-0.5,0.5), resident in HBM)",
+            "collective_backend": (group.backend or "none (single rank)"), "ranks_seen": ranks_seen,
             "config": {"workload": desc, "type": typ, "N": n, "batch_per_gpu": batch, "global_batch": batch * world,
                        "sharding": f"batch-sharded x{world}, no data-path collective", "route": route.strip(),
                        "launches_per_step": launches, "executor": "op-list replay" if (args.no_graph or launches < 8) else "hipGraph replay",
@@ -299,11 +396,20 @@ def main():
             line["roofline"]["per_kernel"] = per_kernel
             line["roofline"]["note"] = ("a launch in the roofline sense is the pass A + pass B pair that moves each point in and out once: "
                                         "algorithmic 16 B/point over the pair; each pass alone moves 16 B/point through the fabric")
-        if not args.no_cpu_baseline and world == 1:
+        if world > 1:
+            line["cpu_baseline"] = None
+            line["cpu_baseline_note"] = "reported at N=1 only (rank 0 of a single-GPU run): see the n_gpus=1 line"
+        elif not args.no_cpu_baseline:
+            # the baseline the north_star names: the reference's Node.js CPU correctness path on the host cores; the C/pthreads
+            # port of the same algorithm is kept beside it.  Reported numbers, never a reason to lose the GPU line.
             try:
-                line["cpu_baseline"] = cpu_baseline(n)
-            except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
-                line["cpu_baseline"] = {"value": None, "unit": "GPoints/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+                line["cpu_baseline"] = cpu_baseline_node(n)
+            except Exception as e:
+                line["cpu_baseline"] = {"value": None, "unit": "GPoints/s", "cores": 0, "kind": "node", "sample": f"failed: {e}"}
+            try:
+                line["cpu_baseline_port"] = cpu_baseline(n, seconds_target=6.0)
+            except Exception as e:
+                line["cpu_baseline_port"] = {"value": None, "unit": "GPoints/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
 
     cmds.release()

@@ -19,7 +19,7 @@ def shard_range(rank, world, global_batch):
 class Group:
     """thin wrapper so bench.py (nccl) and the CPU tests (gloo) share one code path"""
 
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, allow_fallback=False):
         self.rank, self.local_rank, self.world = rank_info()
         self.active = self.world > 1
         self.device = device
@@ -35,8 +35,12 @@ class Group:
                 if self.backend == "nccl" and device is not None:
                     kwargs["device_id"] = device
                 dist.init_process_group(self.backend, **kwargs)
-            except Exception as e:  # RCCL unavailable (e.g. ranks sharing one GPU): the collectives here are only
-                # barriers and scalar reductions, so gloo over CPU tensors is an exact substitute
+            except Exception as e:
+                # RCCL unavailable.  Only the single-GPU rehearsal (ranks sharing one device: allow_fallback) may carry on over
+                # gloo — the collectives here are barriers and scalar reductions, so CPU tensors are an exact substitute there;
+                # on a real multi-GPU run the failure is reported, never papered over.
+                if not allow_fallback or self.backend == "gloo":
+                    raise
                 import sys
                 print(f"[mi355fft.sharding] {self.backend} init failed ({e}); using gloo for barriers/reductions", file=sys.stderr)
                 if dist.is_initialized():
