@@ -365,7 +365,10 @@ def main():
         achieved = bytes_per_point * float(n) * batch / step_dev_s / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
         fused = ("xcd-fused" in route or "xcd-r2c" in route) and launches == 2
-        if fused:
+        resident = "xcd-resident" in route and launches == 2
+        if resident:
+            dominant, dominant_launches = "fft_xcd_res_kernel (transform resident in one XCD's registers + LDS between its passes, hand-offs through the L2)", 1
+        elif fused:
             dominant, dominant_launches = "fft_xcd_fused_kernel (pass A + XCD barrier + pass B in one persistent launch)", 1
         elif "xcd-fused" in route:
             dominant, dominant_launches = "fft_xcd_fused_kernel, then " + route.split("]")[-1].strip() + " kernel", launches - 1
@@ -388,6 +391,9 @@ def main():
                          "kernel": dominant, "algorithmic_bytes_per_point": bytes_per_point, "device_ms_per_step": step_dev_s * 1e3,
                          "avg_launch_us": step_dev_s * 1e6 / max(dominant_launches, 1)},
         }
+        if resident:
+            line["roofline"]["note"] = ("one fft_xcd_res_kernel launch per step carries the whole batch; the only other launch of a step is the 36 KiB zero_kernel "
+                                        "that resets its control block (<3 us), so the step's device time is that kernel's launch duration")
         if fused:
             line["roofline"]["note"] = ("one fft_xcd_fused_kernel launch per step carries the whole batch (column FFTs -> per-XCD workspace slot -> "
                                         "XCD barrier -> four-step roots + row FFTs); the only other launch of a step is the 8 KiB zero_kernel "

@@ -23,7 +23,9 @@ thread_local dim3_t t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 thread_local char* t_smem = nullptr;
 unsigned g_xcds = 2;
 static thread_local pthread_barrier_t* t_barrier = nullptr;
+static thread_local pthread_barrier_t* t_wave_barrier = nullptr;
 void sync_threads() { pthread_barrier_wait(t_barrier); }
+void sync_wave() { pthread_barrier_wait(t_wave_barrier); }
 void yield_thread() { std::this_thread::yield(); }
 }  // namespace emu
 
@@ -40,10 +42,14 @@ struct EmuLauncher {
     char* smem_base = shared.data() + (64 - (reinterpret_cast<uintptr_t>(shared.data()) & 63)) % 64;
     pthread_barrier_t bar;
     pthread_barrier_init(&bar, nullptr, block);
+    const unsigned waves = (block + 63) / 64;
+    std::vector<pthread_barrier_t> wbar(waves);
+    for (unsigned w = 0; w < waves; ++w) pthread_barrier_init(&wbar[w], nullptr, std::min(64u, block - 64 * w));
     std::vector<std::thread> th;
     th.reserve(block);
     auto body = [&](unsigned tid) {
       emu::t_barrier = &bar;
+      emu::t_wave_barrier = &wbar[tid / 64];
       emu::t_smem = smem_base;
       emu::t_blockDim.x = block;
       emu::t_gridDim.x = g;
@@ -57,6 +63,7 @@ struct EmuLauncher {
     for (unsigned t = 0; t < block; ++t) th.emplace_back(body, t);
     for (auto& t : th) t.join();
     pthread_barrier_destroy(&bar);
+    for (auto& w : wbar) pthread_barrier_destroy(&w);
   }
   void copy(void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
 
@@ -70,18 +77,24 @@ struct EmuLauncher {
     std::vector<std::vector<char>> shared(grid, std::vector<char>(bytes));
     std::vector<pthread_barrier_t> bars(grid);
     for (auto& b : bars) pthread_barrier_init(&b, nullptr, block);
+    const unsigned waves = (block + 63) / 64;
+    std::vector<pthread_barrier_t> wbars((size_t)grid * waves);
+    for (unsigned b = 0; b < grid; ++b)
+      for (unsigned w = 0; w < waves; ++w) pthread_barrier_init(&wbars[(size_t)b * waves + w], nullptr, std::min(64u, block - 64 * w));
     std::vector<std::thread> th;
     th.reserve((size_t)grid * block);
     for (unsigned b = 0; b < grid; ++b)
       for (unsigned t = 0; t < block; ++t)
         th.emplace_back([&, b, t] {
           emu::t_barrier = &bars[b];
+          emu::t_wave_barrier = &wbars[(size_t)b * waves + t / 64];
           emu::t_smem = shared[b].data() + (64 - (reinterpret_cast<uintptr_t>(shared[b].data()) & 63)) % 64;
           emu::t_blockDim.x = block; emu::t_gridDim.x = grid; emu::t_threadIdx.x = t; emu::t_blockIdx.x = b;
           kernel(args...);
         });
     for (auto& t : th) t.join();
     for (auto& b : bars) pthread_barrier_destroy(&b);
+    for (auto& w : wbars) pthread_barrier_destroy(&w);
   }
 };
 
@@ -131,6 +144,8 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   opt.compute_units = std::getenv("MI355_EMU_CUS") ? std::atoi(std::getenv("MI355_EMU_CUS")) : 2;
   if (const char* e = std::getenv("MI355_EMU_XCD_FUSED")) opt.xcd_fused = std::atoi(e); else opt.xcd_fused = 0;
   if (const char* e = std::getenv("MI355_EMU_XCD_SPLIT")) opt.xcd_split = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_XCD_RES")) opt.xcd_res = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_XCD_RES_DEPTH")) opt.xcd_res_depth = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_SLOTS")) opt.xcd_slots = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_MIXED_LINES")) opt.mixed_lines = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_MAX_LINE")) opt.max_line = std::atoi(e);

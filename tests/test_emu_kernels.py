@@ -565,3 +565,20 @@ def test_c2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
         got, route, launches = emu.run_plan(desc, x, x.size)
         assert route.startswith(f"xcd-fused[N={label}]") and launches == 2
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused {label} {direction}")
+
+
+@pytest.mark.parametrize("direction,depth,batch", [("forward", 4, 1), ("inverse", 2, 2), ("forward", 1, 2)])
+def test_c2c_xcd_resident_2p20(oracle, monkeypatch, direction, depth, batch):
+    """XCD-resident 1024 x 1024 kernel (kern_xcd_res.hpp): 32 emulated workgroups of 512 threads hold the transform between its
+    passes and hand it over through the exchange channels; depth = channels in flight (1 and 2 exercise the READ-counter gating
+    of a re-used channel buffer), batch 2 the re-use of buffers and LDS across transforms."""
+    monkeypatch.setenv("MI355_EMU_XCD_RES", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_RES_DEPTH", str(depth))
+    monkeypatch.setenv("MI355_EMU_CUS", "32")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    n = 1 << 20
+    x = oracle.random_complex_batch(n, batch, 0xE500 + depth).reshape(-1)
+    desc = _abi.make_desc("c2c", [n], batch, direction, "backward")
+    got, route, launches = emu.run_plan(desc, x, x.size)
+    assert route.startswith("xcd-resident[N=1024x1024,depth=%d]" % depth) and launches == 2, route
+    check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"xcd-resident {direction} depth={depth}")

@@ -142,6 +142,23 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
+@pytest.mark.parametrize("depth", [4, 2, 1])
+def test_c2c_xcd_resident(fft, dev, oracle, monkeypatch, depth):
+    """N = 2^20 on the XCD-resident kernel (kern_xcd_res.hpp): the transform is handed between the 32 workgroups of an XCD through
+    L2-resident exchange channels (depth = channels in flight).  11 transforms over 8 XCD groups: ragged last round, buffers and
+    counters re-used across transforms; every transform against the oracle, both directions."""
+    if dev.info()["compute_units"] % 32:
+        pytest.skip("needs whole XCDs of 32 CUs")
+    monkeypatch.setenv("MI355FFT_XCD_RES", "1")
+    monkeypatch.setenv("MI355FFT_XCD_RES_DEPTH", str(depth))
+    n, batch = 1 << 20, 11
+    x = oracle.random_complex_batch(n, batch, 0xE500 + depth).reshape(-1)
+    for direction in ("forward", "inverse"):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
+        assert route.startswith("xcd-resident[N=1024x1024,depth=%d]" % depth) and launches == 2, route
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} {direction}")
+
+
 @pytest.mark.parametrize("fused", [0, 1])
 @pytest.mark.parametrize("shape,batch", [([256, 256], 40), ([512, 512], 20), ([1024, 1024], 5), ([256, 256, 4], 3),
                                          ([512, 256], 20), ([256, 512], 20), ([512, 1024], 6), ([1024, 512], 6)])

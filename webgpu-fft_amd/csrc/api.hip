@@ -249,9 +249,8 @@ MI_API int mi355fft_plan_create(mi355fft_device* dev, const mi355fft_plan_desc* 
     HipLauncher l;
     l.sticky = dev->sticky;
     l.prepare_only = true;
-    for (const Step& s : p->ir.steps) if (s.kind == ST_XCD_FUSED) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); op.ptr[4] = p->table; (void)op; }
     std::vector<RecordedOp> probe;
-    for (const Step& s : p->ir.steps) if (s.kind == ST_LINES || s.kind == ST_XCD_FUSED) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
+    for (const Step& s : p->ir.steps) if (s.kind == ST_LINES || s.kind == ST_XCD_FUSED || s.kind == ST_XCD_RES) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
     const int prc = replay(probe, l);
     if (prc) { (void)hipFree(p->table); return prc; }
   }
@@ -406,7 +405,7 @@ MI_API int mi355fft_queue_submit(mi355fft_device* dev, mi355fft_commands* cmds) 
   if (!dev || !cmds) return fail(MI355FFT_ERR_INVALID, "submit: device and command list are required");
   if (cmds->dev != dev) return fail(MI355FFT_ERR_INVALID, "command list belongs to a different device");
   HIP_TRY(hipSetDevice(dev->ordinal));
-  for (const RecordedOp& op : cmds->ops) if (op.step.kind == ST_XCD_FUSED) dev->sticky_armed = true;
+  for (const RecordedOp& op : cmds->ops) if (op.step.kind == ST_XCD_FUSED || op.step.kind == ST_XCD_RES) dev->sticky_armed = true;
   if (cmds->exec) { HIP_TRY(hipGraphLaunch(cmds->exec, dev->stream)); return MI355FFT_OK; }
   HipLauncher l;
   l.stream = dev->stream;

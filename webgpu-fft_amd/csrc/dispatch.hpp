@@ -15,6 +15,7 @@
 #include "kern_mixed.hpp"
 #include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
+#include "kern_xcd_res.hpp"
 #include "plan.hpp"
 
 namespace mi355 {
@@ -163,6 +164,22 @@ template <class L> bool launch_xcd_fused(int id, const XcdFusedArgs& a, unsigned
 #endif
 }
 
+// XCD-resident kernel (kern_xcd_res.hpp): variant bit 0 = inverse, bit 1 = data-movement skeleton.  Own translation unit
+// (xcd_res_kernel.hip) in the product build, like the fused instances.
+template <class L> bool launch_xcd_res(int variant, const XcdFusedArgs& a, unsigned grid, L& l);
+#if defined(MI355_XCD_RES_DEFINE_INSTANCES) || defined(MI355_HOST_EMU)
+template <class L> bool launch_xcd_res(int variant, const XcdFusedArgs& a, unsigned grid, L& l) {
+  constexpr unsigned T = (unsigned)XcdResCfg::THREADS, S = (unsigned)XcdResCfg::LDS_BYTES;
+  switch (variant) {
+    case 0: l.launch_concurrent(fft_xcd_res_kernel<false, true>, grid, T, S, a); return true;
+    case 1: l.launch_concurrent(fft_xcd_res_kernel<true, true>, grid, T, S, a); return true;
+    case 2: l.launch_concurrent(fft_xcd_res_kernel<false, false>, grid, T, S, a); return true;
+    case 3: l.launch_concurrent(fft_xcd_res_kernel<true, false>, grid, T, S, a); return true;
+  }
+  return false;
+}
+#endif
+
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
   switch (radix) {
 #define MI_STAGE_CASE(R) case R: l.launch(stockham_stage_kernel<R>, grid, 256u, 0u, a); return true;
@@ -178,6 +195,7 @@ template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned gri
 template <class L, class LinesFn, class XcdFn>
 bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, XcdFn&& xcd_fn) {
   switch (s.kind) {
+    case ST_XCD_RES:
     case ST_XCD_FUSED: {
       XcdFusedArgs a{};
       a.in = (const cf*)ptr[0]; a.out = (cf*)ptr[1]; a.wslots = (cf*)ptr[2]; a.ctl = (XcdCtl*)ptr[3];
@@ -189,6 +207,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.sticky_error = l.sticky_error_word();
       a.spin_limit = 4000000u;
       a.split = (unsigned)s.i[8]; a.slots = (unsigned)s.i[11]; a.solo = (unsigned)s.i[12];
+      if (s.kind == ST_XCD_RES) return launch_xcd_res(s.variant, a, s.grid, l);
       return xcd_fn(s.variant, a, s.grid);
     }
     case ST_LINES: {

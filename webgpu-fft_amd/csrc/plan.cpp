@@ -134,7 +134,10 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= 0) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_RES_DEPTH")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_res_depth = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 32) o.xcd_split = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_2D")) o.xcd_2d = std::atoi(s);
@@ -234,6 +237,9 @@ struct Builder {
     if (m.lds_bytes > 0) per_cu = std::min<int64_t>(per_cu, (160 * 1024) / m.lds_bytes);
     per_cu = std::min<int64_t>(per_cu, 2048 / m.threads);
     per_cu = std::max<int64_t>(per_cu, 1);
+    // lines_tiles_per_wg > 0: a short-lived workgroup per `lines_tiles_per_wg` tiles instead of a resident grid walking the batch
+    // (one-shot grids stream at 6.2-6.5 TB/s where persistent loops reach 5.3-5.5: profiles/r02_copy_ceiling.log)
+    if (opt.lines_tiles_per_wg > 0) return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + opt.lines_tiles_per_wg - 1) / opt.lines_tiles_per_wg, (int64_t)1 << 30));
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, per_cu * opt.compute_units));
   }
 
@@ -459,6 +465,28 @@ struct Builder {
         ir.route += "columns-ragged[N=" + std::to_string(N) + ",S=" + std::to_string(S) + "] ";
         return MI355FFT_OK;
       }
+    }
+    if (!opt.force_generic && S == 1 && N == (1 << 20) && opt.xcd_res && !opt.only_pass && opt.compute_units % 32 == 0) {
+      // XCD-resident route (kern_xcd_res.hpp): the transform stays in the registers and LDS of one XCD's 32 workgroups between
+      // its passes; hand-offs go through a 4 MiB L2-resident exchange buffer per XCD.  One workgroup per CU, all co-resident.
+      const int shift = 10;
+      std::vector<float2h> lo((size_t)1 << shift), hi((size_t)(N >> shift));
+      for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
+      for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
+      const LineKernelMeta mt = make_meta(0, 1024, 32, 32, 1, 16, true, true, false, false, 0);
+      const PtrRef ta = line_tables(mt), tlo = add_table(lo), thi = add_table(hi);
+      const PtrRef wslots = alloc_work((uint64_t)16 * 4 * (1 << 20));   // 4 channels of 1 MiB per XCC id (16 ids)
+      const PtrRef ctl = alloc_work(40960);
+      { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
+      Step& st = push(ST_XCD_RES);
+      st.variant = (inverse ? 1 : 0) + (opt.xcd_res == 2 ? 2 : 0);
+      st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+      st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N; st.i[10] = N;
+      st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = opt.xcd_res_depth; st.i[11] = 1; st.i[12] = 0;
+      st.f[0] = scale;
+      st.grid = (unsigned)opt.compute_units;
+      ir.route += "xcd-resident[N=1024x1024,depth=" + std::to_string(opt.xcd_res_depth) + (opt.xcd_res == 2 ? ",skeleton" : "") + "] ";
+      return MI355FFT_OK;
     }
     if (!opt.force_generic && S == 1 && p2 && N >= 4096 && opt.xcd_fused && !opt.only_pass) {
       // XCD-fused route: both passes in one persistent launch, one transform per XCD at a time (kern_xcd.hpp)

@@ -82,7 +82,7 @@ struct PtrRef {
 
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
-  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED, ST_TRIG_PRE, ST_TRIG_POST
+  ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED, ST_TRIG_PRE, ST_TRIG_POST, ST_XCD_RES
 };
 
 // One recorded launch, pointers still symbolic.  Scalar fields are kind-specific (see dispatch.hpp).
@@ -108,8 +108,11 @@ struct PlanIR {
 struct PlannerOptions {
   uint64_t chunk_bytes = 1ull << 30;   // two-pass: bytes of inter-pass intermediate per launch pair (measured: larger is faster)
   int compute_units = 256;
+  int lines_tiles_per_wg = 0;          // line kernels: 0 = resident grid (CUs x workgroups per CU) walking the tiles; k > 0 = one workgroup per k tiles
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
+  int xcd_res = 0;                     // N = 2^20: XCD-resident kernel (kern_xcd_res.hpp): 1 on, 2 = its data-movement skeleton without arithmetic (measurement only)
+  int xcd_res_depth = 4;               // exchange channels in flight per XCD (1, 2, 4): 1 MiB of L2-resident buffer each
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)

@@ -37,6 +37,7 @@ extern thread_local dim3_t t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
 extern thread_local char* t_smem;
 extern unsigned g_xcds;   // emulated XCD count: block b reports XCC id b % g_xcds
 void sync_threads();
+void sync_wave();    // the 64 emulated threads of one wave (kern_xcd_res.hpp: waves of a workgroup wait on different counters)
 void yield_thread();
 }  // namespace emu
 #define __global__
