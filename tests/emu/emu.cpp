@@ -188,6 +188,22 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   return 0;
 }
 
+// Planner only (host logic tests: routes, guards, workspace sizes) — nothing is run, so shapes far beyond host memory are fine.
+int emu_plan_only(const mi355fft_plan_desc* desc, int compute_units, char* err, size_t err_bytes, char* route, size_t route_bytes, int* launches,
+                  uint64_t* work_bytes) {
+  using namespace mi355;
+  PlannerOptions opt = planner_options_from_env();
+  opt.compute_units = compute_units > 0 ? compute_units : 256;
+  PlanIR ir;
+  std::string e;
+  const int rc = build_plan(*desc, opt, ir, e);
+  if (rc) { std::snprintf(err, err_bytes, "%s", e.c_str()); return rc; }
+  if (route) std::snprintf(route, route_bytes, "%s", ir.route.c_str());
+  if (launches) *launches = (int)ir.steps.size();
+  if (work_bytes) *work_bytes = ir.work_bytes;
+  return 0;
+}
+
 // support kernels: PRNG twin + reductions
 int emu_fill_random(float* out, uint64_t row_floats, uint64_t rows, uint32_t seed0, uint64_t first_transform) {
   EmuLauncher l;

@@ -27,6 +27,9 @@ def lib():
         L.emu_check_registry.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
         L.emu_fill_random.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
         L.emu_diff_sumsq.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_uint64, ctypes.POINTER(ctypes.c_double)]
+        L.emu_plan_only.restype = ctypes.c_int
+        L.emu_plan_only.argtypes = [ctypes.POINTER(_abi.PlanDesc), ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
         _LIB = L
     return _LIB
 
@@ -35,6 +38,18 @@ class EmuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(msg)
         self.code = code
+
+
+def plan_only(desc, compute_units=256):
+    """The product planner (MI355FFT_* environment as the library reads it) without running anything: (route, launches, workspace bytes)."""
+    err = ctypes.create_string_buffer(1024)
+    route = ctypes.create_string_buffer(2048)
+    launches = ctypes.c_int(0)
+    work = ctypes.c_uint64(0)
+    rc = lib().emu_plan_only(ctypes.byref(desc), compute_units, err, 1024, route, 2048, ctypes.byref(launches), ctypes.byref(work))
+    if rc != 0:
+        raise EmuError(rc, err.value.decode())
+    return route.value.decode(), launches.value, work.value
 
 
 def run_plan(desc, x, out_floats, kernel=None, force_generic=False, chunk_bytes=0, out_init=None):

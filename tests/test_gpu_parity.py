@@ -757,3 +757,69 @@ def test_torch_fft_cross_check(fft, dev, oracle):
     t = torch.from_numpy(x.reshape(batch, n, 2).copy()).cuda()
     ref = torch.view_as_real(torch.fft.fft(torch.view_as_complex(t), dim=1)).cpu().numpy().reshape(-1)
     assert oracle.rel_l2(got, ref) < 2e-6
+
+
+# ---- safety paths of the kernels whose workgroups wait for each other ---------------------------------------
+def test_xcd_timeout_fails_the_readback_then_falls_back(fft, dev, oracle, monkeypatch):
+    """A bounded wait that gives up (forced: one poll) must never be read back as a result: submit -> downloadComplex is the
+    reference's normal flow (no onSubmittedWorkDone), so the readback itself reports it.  After that the device plans, and the
+    same plan at its next exec runs, the routes without cross-workgroup synchronisation — and the result is right."""
+    import mi355fft
+    d2 = mi355fft.Device(0)          # own device object: the fallback state is per device and must not leak into other tests
+    try:
+        monkeypatch.setenv("MI355FFT_XCD_SPIN_LIMIT", "1")
+        n, batch = 1 << 20, 16
+        x = oracle.random_complex_batch(n, batch, 0x7117).reshape(-1)
+        inp = mi355fft.uploadComplex(d2, x)
+        out = d2.createBuffer({"size": x.nbytes})
+        plan = mi355fft.createPlan(d2, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
+        assert plan.describe()[0].startswith("xcd-fused["), plan.describe()
+        enc = d2.createCommandEncoder()
+        plan.exec(enc, {"input": inp, "output": out})
+        cb = enc.finish()
+        d2.queue.submit([cb])
+        with pytest.raises(mi355fft.Mi355Error, match="gave up waiting"):
+            mi355fft.downloadF32(d2, out, 2 * n)                       # NOT preceded by a queue wait
+        monkeypatch.delenv("MI355FFT_XCD_SPIN_LIMIT")
+        enc = d2.createCommandEncoder()
+        plan.exec(enc, {"input": inp, "output": out})                  # re-planned here
+        assert plan.describe()[0].startswith("two-pass["), plan.describe()
+        with pytest.raises(mi355fft.Mi355Error, match="destroyed plan or buffer"):
+            d2.queue.submit([cb])                                      # the old list points into the old tables
+        d2.queue.submit([enc.finish()])
+        got = mi355fft.downloadF32(d2, out, 2 * n * batch)
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, "forward", "none"), "after the fallback")
+        p2 = mi355fft.createPlan(d2, {"type": "c2c", "shape": [1 << 19], "batch": 2, "direction": "forward", "normalize": "none"})
+        assert p2.describe()[0].startswith("two-pass["), p2.describe()   # new plans on this device too
+        p3 = mi355fft.createPlan(d2, {"type": "c2c", "shape": [1 << 16], "batch": 2, "direction": "forward", "normalize": "none"})
+        assert p3.describe()[0].startswith("xcd-solo["), p3.describe()   # no cross-workgroup waits: stays
+        for p in (plan, p2, p3):
+            p.destroy()
+        inp.destroy()
+        out.destroy()
+    finally:
+        d2.close()
+
+
+def test_submit_after_destroy_is_refused(fft, dev, oracle):
+    """a recorded command list holds raw pointers into the plan's tables and the caller's buffers: once either is destroyed the
+    list can no longer be submitted (the reference raises a validation error; here MI355FFT_ERR_DESTROYED)"""
+    n = 1024
+    x = oracle.random_complex_batch(n, 4, 0xDE57).reshape(-1)
+    for victim in ("plan", "output"):
+        inp = fft.uploadComplex(dev, x)
+        out = dev.createBuffer({"size": x.nbytes})
+        plan = fft.createPlan(dev, {"type": "c2c", "shape": [n], "batch": 4, "direction": "forward", "normalize": "none"})
+        enc = dev.createCommandEncoder()
+        plan.exec(enc, {"input": inp, "output": out})
+        cb = enc.finish()
+        dev.queue.submit([cb])
+        dev.queue.onSubmittedWorkDone()
+        (plan if victim == "plan" else out).destroy()
+        with pytest.raises(fft.Mi355Error, match="destroyed plan or buffer"):
+            dev.queue.submit([cb])
+        cb.release()
+        plan.destroy()
+        inp.destroy()
+        if victim == "plan":
+            out.destroy()

@@ -101,3 +101,27 @@ def test_no_cpu_fallback_without_a_gpu():
     with pytest.raises(mi355fft.Mi355Error) as e:
         mi355fft.Device(0)
     assert e.value.code == _abi.ERR_HIP
+
+
+def test_strided_axis_beyond_32_bit_span_stays_off_the_column_line_kernels():
+    """kern_lines.hpp addresses a column tile with 32-bit element offsets (idx * S): an axis whose plane spans >= 2^32 elements
+    must not take that route (it would wrap silently); the stage route indexes with 64 bits.  Planner only — nothing is run."""
+    import emu_harness as emu
+    from mi355fft import _abi
+    small = _abi.make_desc("c2c", [1 << 16, 1024], 1, "forward", "none")          # axis 1: N = 1024 over S = 2^16 -> 2^26 elements
+    route, _, _ = emu.plan_only(small)
+    assert "columns[N=1024,S=65536]" in route, route
+    big = _abi.make_desc("c2c", [1 << 22, 1024], 1, "forward", "none")            # axis 1: N = 1024 over S = 2^22 -> 2^32 elements (32 GiB)
+    route, _, _ = emu.plan_only(big)
+    assert "columns[" not in route and "stages[" in route, route
+
+
+def test_xcd_resident_route_is_opt_in_and_needs_whole_xcds(monkeypatch):
+    import emu_harness as emu
+    from mi355fft import _abi
+    d = _abi.make_desc("c2c", [1 << 20], 64, "forward", "none")
+    assert emu.plan_only(d)[0].startswith("xcd-fused[N=1024x1024]")
+    monkeypatch.setenv("MI355FFT_XCD_RES", "1")
+    route, launches, work = emu.plan_only(d)
+    assert route.startswith("xcd-resident[N=1024x1024,depth=4]") and launches == 2 and work >= 16 * 4 * (1 << 20)
+    assert emu.plan_only(d, compute_units=250)[0].startswith("xcd-fused[")      # not a multiple of 32 CUs: no resident groups

@@ -48,31 +48,44 @@ struct mi355fft_device {
   std::string arch;
   unsigned* sticky = nullptr;     // device word raised by kernels whose bounded waits timed out (kern_xcd.hpp)
   bool sticky_armed = false;      // a kernel that can raise it has been submitted since the last check
+  bool xcd_disabled = false;      // a bounded wait HAS timed out on this device (its workgroups were not co-resident: another
+                                  // stream / process / CU mask shares the GPU): new plans, and existing ones at their next exec,
+                                  // take the routes without cross-workgroup synchronisation
 };
+// Recorded command lists hold raw device pointers into plans (tables, workspace arena) and caller buffers.  Each of those
+// owners carries an "alive" token; a command list keeps a copy of the token of everything it references and submit refuses a
+// list whose plan or buffer has been destroyed (the reference raises a validation error there; writing into freed or
+// re-allocated HBM is not an option).
+typedef std::shared_ptr<bool> AliveToken;
 struct mi355fft_buffer {
   mi355fft_device* dev = nullptr;
   void* ptr = nullptr;
   uint64_t bytes = 0;
   bool owned = false;
+  AliveToken alive = std::make_shared<bool>(true);
 };
 struct RecordedOp { Step step; void* ptr[5]; };
 struct mi355fft_encoder {
   mi355fft_device* dev = nullptr;
   std::vector<RecordedOp> ops;
+  std::vector<AliveToken> deps;
 };
 struct mi355fft_commands {
   mi355fft_device* dev = nullptr;
   std::vector<RecordedOp> ops;
+  std::vector<AliveToken> deps;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
 };
 struct mi355fft_plan {
   mi355fft_device* dev = nullptr;
+  AliveToken alive = std::make_shared<bool>(true);
   PlanIR ir;
   void* table = nullptr;
   void* arena = nullptr;
   uint64_t arena_bytes = 0;
   bool destroyed = false;
+  bool uses_xcd_sync = false;     // has a step whose workgroups wait for each other (needs co-residency)
 };
 
 namespace {
@@ -94,6 +107,27 @@ int replay(const std::vector<RecordedOp>& ops, HipLauncher& l) {
                                   [&](int id, const XcdFusedArgs& a, unsigned grid) { return launch_xcd_fused(id, a, grid, l); });
     if (!ok) return fail(MI355FFT_ERR_UNSUPPORTED, "no kernel instance for step kind %d variant %d", (int)op.step.kind, op.step.variant);
     if (l.status != hipSuccess) return fail(MI355FFT_ERR_HIP, "HIP error %d (%s) launching step kind %d", (int)l.status, hipGetErrorString(l.status), (int)op.step.kind);
+  }
+  return MI355FFT_OK;
+}
+
+// Synchronises the device stream and reports a bounded wait that gave up inside a kernel (kern_xcd.hpp / kern_xcd_res.hpp raise
+// the sticky word).  Every host-visible hand-over of results goes through here — queue_wait, buffer reads, reductions — so a
+// timed-out submit can never be read back as if it had succeeded.
+int sync_and_check(mi355fft_device* dev) {
+  HIP_TRY(hipSetDevice(dev->ordinal));
+  HIP_TRY(hipStreamSynchronize(dev->stream));
+  if (dev->sticky_armed) {
+    dev->sticky_armed = false;
+    unsigned word = 0;
+    HIP_TRY(hipMemcpy(&word, dev->sticky, sizeof word, hipMemcpyDeviceToHost));
+    if (word) {
+      (void)hipMemset(dev->sticky, 0, sizeof word);
+      dev->xcd_disabled = true;
+      return fail(MI355FFT_ERR_HIP, "XCD-fused FFT kernel gave up waiting (%s%s%s): its workgroups were not all co-resident; results of that submit are "
+                  "invalid.  Plans on this device now use the routes without cross-workgroup synchronisation: record and submit again.", (word & 1u) ? "registration " : "", (word & 2u) ? "barrier " : "",
+                  (word & 4u) ? "group-size" : "");
+    }
   }
   return MI355FFT_OK;
 }
@@ -192,9 +226,10 @@ MI_API int mi355fft_buffer_wrap(mi355fft_device* dev, void* device_ptr, uint64_t
 
 MI_API int mi355fft_buffer_free(mi355fft_buffer* buf) {
   if (!buf) return MI355FFT_OK;
+  *buf->alive = false;                              // command lists that reference it can no longer be submitted
   if (buf->owned && buf->ptr) {
     (void)hipSetDevice(buf->dev->ordinal);
-    (void)hipStreamSynchronize(buf->dev->stream);   // submitted work may still use it
+    (void)hipStreamSynchronize(buf->dev->stream);   // submitted work may still use it (a sticky error stays armed for the next check)
     (void)hipFree(buf->ptr);
   }
   delete buf;
@@ -220,40 +255,71 @@ MI_API int mi355fft_buffer_read(mi355fft_buffer* buf, uint64_t offset_bytes, voi
   if (offset_bytes + bytes > buf->bytes) return fail(MI355FFT_ERR_INVALID, "readback: range [%llu, %llu) exceeds buffer size %llu",
                                                      (unsigned long long)offset_bytes, (unsigned long long)(offset_bytes + bytes), (unsigned long long)buf->bytes);
   if (!bytes) return MI355FFT_OK;
-  HIP_TRY(hipSetDevice(buf->dev->ordinal));
-  HIP_TRY(hipStreamSynchronize(buf->dev->stream));
+  { const int rc = sync_and_check(buf->dev); if (rc) return rc; }
   HIP_TRY(hipMemcpy(dst, (const char*)buf->ptr + offset_bytes, bytes, hipMemcpyDeviceToHost));
   return MI355FFT_OK;
 }
 
 // ---- plans -----------------------------------------------------------------------------------------
-MI_API int mi355fft_plan_create(mi355fft_device* dev, const mi355fft_plan_desc* desc, mi355fft_plan** out) {
-  if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
-  if (!desc || !out) return fail(MI355FFT_ERR_INVALID, "createPlan: options and out pointer are required");
-  *out = nullptr;
-  std::unique_ptr<mi355fft_plan> p(new mi355fft_plan());
-  p->dev = dev;
+namespace {
+bool step_needs_coresidency(const Step& s) { return s.kind == ST_XCD_RES || (s.kind == ST_XCD_FUSED && s.i[12] == 0); }
+
+// Plans `desc` for `dev` into p->ir and uploads the tables.  Steps whose workgroups synchronise with each other are only kept
+// when the runtime's occupancy answer covers the grid the planner sized for them (all of it resident at once); otherwise, and
+// on a device where such a kernel has already timed out, the plan is built again without those routes.
+int build_and_upload(mi355fft_device* dev, const mi355fft_plan_desc& desc, mi355fft_plan* p) {
   PlannerOptions opt = planner_options_from_env();
   opt.compute_units = dev->compute_units;
-  std::string err;
-  const int rc = build_plan(*desc, opt, p->ir, err);
-  if (rc) return fail(rc, "%s", err.c_str());
   HIP_TRY(hipSetDevice(dev->ordinal));
-  const size_t tbytes = p->ir.table.size() * sizeof(float2h);
-  hipError_t e = hipMalloc(&p->table, tbytes);
-  if (e != hipSuccess) return fail(MI355FFT_ERR_NOMEM, "hipMalloc(twiddle tables, %zu bytes) failed: %s", tbytes, hipGetErrorString(e));
-  e = hipMemcpy(p->table, p->ir.table.data(), tbytes, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(p->table); return fail(MI355FFT_ERR_HIP, "uploading twiddle tables failed: %s", hipGetErrorString(e)); }
-  // raise dynamic-LDS limits now: hipFuncSetAttribute is not legal inside a later stream capture
-  {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (dev->xcd_disabled || attempt == 1) opt.xcd_shared = 0;
+    p->ir = PlanIR();
+    std::string err;
+    const int rc = build_plan(desc, opt, p->ir, err);
+    if (rc) return fail(rc, "%s", err.c_str());
+    // raise dynamic-LDS limits now (hipFuncSetAttribute is not legal inside a later stream capture) and check co-residency
     HipLauncher l;
     l.sticky = dev->sticky;
     l.prepare_only = true;
     std::vector<RecordedOp> probe;
     for (const Step& s : p->ir.steps) if (s.kind == ST_LINES || s.kind == ST_XCD_FUSED || s.kind == ST_XCD_RES) { RecordedOp op; op.step = s; std::memset(op.ptr, 0, sizeof op.ptr); probe.push_back(op); }
     const int prc = replay(probe, l);
-    if (prc) { (void)hipFree(p->table); return prc; }
+    if (prc) return prc;
+    bool fits = true;
+    p->uses_xcd_sync = false;
+    for (const Step& s : p->ir.steps) {
+      if (!step_needs_coresidency(s)) continue;
+      p->uses_xcd_sync = true;
+      HipLauncher q;
+      q.sticky = dev->sticky;
+      q.occupancy_query = true;
+      std::vector<RecordedOp> one(1);
+      one[0].step = s;
+      std::memset(one[0].ptr, 0, sizeof one[0].ptr);
+      const int qrc = replay(one, q);
+      if (qrc) return qrc;
+      const long long need = ((long long)s.grid + dev->compute_units - 1) / dev->compute_units;
+      if (q.min_blocks_per_cu < need) fits = false;
+    }
+    if (fits || attempt == 1) break;
   }
+  const size_t tbytes = p->ir.table.size() * sizeof(float2h);
+  hipError_t e = hipMalloc(&p->table, tbytes);
+  if (e != hipSuccess) return fail(MI355FFT_ERR_NOMEM, "hipMalloc(twiddle tables, %zu bytes) failed: %s", tbytes, hipGetErrorString(e));
+  e = hipMemcpy(p->table, p->ir.table.data(), tbytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(p->table); p->table = nullptr; return fail(MI355FFT_ERR_HIP, "uploading twiddle tables failed: %s", hipGetErrorString(e)); }
+  return MI355FFT_OK;
+}
+}  // namespace
+
+MI_API int mi355fft_plan_create(mi355fft_device* dev, const mi355fft_plan_desc* desc, mi355fft_plan** out) {
+  if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
+  if (!desc || !out) return fail(MI355FFT_ERR_INVALID, "createPlan: options and out pointer are required");
+  *out = nullptr;
+  std::unique_ptr<mi355fft_plan> p(new mi355fft_plan());
+  p->dev = dev;
+  const int rc = build_and_upload(dev, *desc, p.get());
+  if (rc) return rc;
   *out = p.release();
   return MI355FFT_OK;
 }
@@ -277,6 +343,21 @@ MI_API int mi355fft_plan_exec(mi355fft_plan* plan, mi355fft_encoder* enc, const 
   if (!enc) return fail(MI355FFT_ERR_INVALID, "exec requires a command encoder");
   if (!args || args->struct_size != sizeof(mi355fft_exec_args)) return fail(MI355FFT_ERR_INVALID, "exec options missing or ABI size mismatch");
   if (enc->dev != plan->dev) return fail(MI355FFT_ERR_INVALID, "encoder and plan belong to different devices");
+  if (plan->dev->xcd_disabled && plan->uses_xcd_sync) {
+    // a kernel with cross-workgroup waits has timed out on this device: rebuild this plan on the routes without them.  Command
+    // lists recorded from the old steps reference the old tables / arena and can no longer be submitted.
+    (void)hipSetDevice(plan->dev->ordinal);
+    (void)hipStreamSynchronize(plan->dev->stream);
+    *plan->alive = false;
+    plan->alive = std::make_shared<bool>(true);
+    if (plan->table) (void)hipFree(plan->table);
+    if (plan->arena) (void)hipFree(plan->arena);
+    plan->table = plan->arena = nullptr;
+    plan->arena_bytes = 0;
+    const mi355fft_plan_desc desc_copy = plan->ir.desc;
+    const int rrc = build_and_upload(plan->dev, desc_copy, plan);
+    if (rrc) return rrc;
+  }
   const mi355fft_plan_desc& d = plan->ir.desc;
   if (!args->input) return fail(MI355FFT_ERR_INVALID, "exec requires input");
   if (!d.in_place && !args->output) return fail(MI355FFT_ERR_INVALID, "exec requires output when inPlace=false");
@@ -325,11 +406,17 @@ MI_API int mi355fft_plan_exec(mi355fft_plan* plan, mi355fft_encoder* enc, const 
     for (int i = 0; i < 5; ++i) op.ptr[i] = s.p[i].buf == BUF_NONE ? nullptr : base[s.p[i].buf] + s.p[i].off;
     enc->ops.push_back(op);
   }
+  enc->deps.push_back(plan->alive);
+  enc->deps.push_back(args->input->alive);
+  enc->deps.push_back(out->alive);
+  if (args->kernel) enc->deps.push_back(args->kernel->alive);
+  if (args->temp && work == args->temp->ptr) enc->deps.push_back(args->temp->alive);
   return MI355FFT_OK;
 }
 
 MI_API int mi355fft_plan_destroy(mi355fft_plan* plan) {
   if (!plan || plan->destroyed) return MI355FFT_OK;
+  *plan->alive = false;
   (void)hipSetDevice(plan->dev->ordinal);
   (void)hipStreamSynchronize(plan->dev->stream);
   if (plan->table) (void)hipFree(plan->table);
@@ -367,6 +454,8 @@ MI_API int mi355fft_encoder_copy_buffer(mi355fft_encoder* enc, mi355fft_buffer* 
   op.ptr[0] = (char*)src->ptr + src_offset;
   op.ptr[1] = (char*)dst->ptr + dst_offset;
   enc->ops.push_back(op);
+  enc->deps.push_back(src->alive);
+  enc->deps.push_back(dst->alive);
   return MI355FFT_OK;
 }
 
@@ -379,6 +468,7 @@ MI_API int mi355fft_encoder_finish(mi355fft_encoder* enc, int use_graph, mi355ff
   mi355fft_commands* c = new mi355fft_commands();
   c->dev = enc->dev;
   c->ops.swap(enc->ops);
+  c->deps.swap(enc->deps);
   // use_graph: 0 = op list, 1 = hipGraph, 2 = auto: a graph pays off once a list has many launches (measured:
   // a 1-launch list replays in 5 us as an op list and 11 us as a graph; 64-launch lists are on par)
   if (use_graph == 2) use_graph = c->ops.size() >= 8 ? 1 : 0;
@@ -404,6 +494,7 @@ MI_API int mi355fft_encoder_finish(mi355fft_encoder* enc, int use_graph, mi355ff
 MI_API int mi355fft_queue_submit(mi355fft_device* dev, mi355fft_commands* cmds) {
   if (!dev || !cmds) return fail(MI355FFT_ERR_INVALID, "submit: device and command list are required");
   if (cmds->dev != dev) return fail(MI355FFT_ERR_INVALID, "command list belongs to a different device");
+  for (const AliveToken& t : cmds->deps) if (!*t) return fail(MI355FFT_ERR_DESTROYED, "command buffer references a destroyed plan or buffer");
   HIP_TRY(hipSetDevice(dev->ordinal));
   for (const RecordedOp& op : cmds->ops) if (op.step.kind == ST_XCD_FUSED || op.step.kind == ST_XCD_RES) dev->sticky_armed = true;
   if (cmds->exec) { HIP_TRY(hipGraphLaunch(cmds->exec, dev->stream)); return MI355FFT_OK; }
@@ -423,19 +514,7 @@ MI_API int mi355fft_commands_release(mi355fft_commands* cmds) {
 
 MI_API int mi355fft_queue_wait(mi355fft_device* dev) {
   if (!dev) return fail(MI355FFT_ERR_INVALID, "Expected a device");
-  HIP_TRY(hipSetDevice(dev->ordinal));
-  HIP_TRY(hipStreamSynchronize(dev->stream));
-  if (dev->sticky_armed) {
-    dev->sticky_armed = false;
-    unsigned word = 0;
-    HIP_TRY(hipMemcpy(&word, dev->sticky, sizeof word, hipMemcpyDeviceToHost));
-    if (word) {
-      (void)hipMemset(dev->sticky, 0, sizeof word);
-      return fail(MI355FFT_ERR_HIP, "XCD-fused FFT kernel gave up waiting (%s%s): its workgroups were not all co-resident; results of that submit are "
-                  "invalid.  Set MI355FFT_XCD_FUSED=0 to use the two-kernel route.", (word & 1u) ? "registration " : "", (word & 2u) ? "barrier" : "");
-    }
-  }
-  return MI355FFT_OK;
+  return sync_and_check(dev);
 }
 
 // ---- synthetic inputs / reductions -----------------------------------------------------------------
@@ -468,9 +547,11 @@ MI_API int mi355fft_diff_sumsq(mi355fft_device* dev, mi355fft_buffer* a, uint64_
                      b ? (const float*)((const char*)b->ptr + b_offset_bytes) : (const float*)nullptr, alpha, (unsigned long long)count, partial);
   hipError_t e = hipGetLastError();
   std::vector<double> host(grid);
-  if (e == hipSuccess) e = hipStreamSynchronize(dev->stream);
-  if (e == hipSuccess) e = hipMemcpy(host.data(), partial, grid * sizeof(double), hipMemcpyDeviceToHost);
+  int sticky_rc = MI355FFT_OK;
+  if (e == hipSuccess) sticky_rc = sync_and_check(dev);     // the reduced buffers may be results of a submit that timed out
+  if (e == hipSuccess && !sticky_rc) e = hipMemcpy(host.data(), partial, grid * sizeof(double), hipMemcpyDeviceToHost);
   (void)hipFree(partial);
+  if (sticky_rc) return sticky_rc;
   if (e != hipSuccess) return fail(MI355FFT_ERR_HIP, "sumsq failed: %s", hipGetErrorString(e));
   double s = 0.0;
   for (double v : host) s += v;

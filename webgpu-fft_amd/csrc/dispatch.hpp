@@ -175,6 +175,8 @@ template <class L> bool launch_xcd_res(int variant, const XcdFusedArgs& a, unsig
     case 1: l.launch_concurrent(fft_xcd_res_kernel<true, true>, grid, T, S, a); return true;
     case 2: l.launch_concurrent(fft_xcd_res_kernel<false, false>, grid, T, S, a); return true;
     case 3: l.launch_concurrent(fft_xcd_res_kernel<true, false>, grid, T, S, a); return true;
+    case 4: l.launch_concurrent(fft_xcd_res_kernel<false, true, true>, grid, T, S, a); return true;    // diagnostic: in-kernel phase stamps
+    case 6: l.launch_concurrent(fft_xcd_res_kernel<false, false, true>, grid, T, S, a); return true;
   }
   return false;
 }
@@ -205,7 +207,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.in_pitch = s.i[9]; a.out_pitch = s.i[10];
       a.scale = s.f[0];
       a.sticky_error = l.sticky_error_word();
-      a.spin_limit = 4000000u;
+      a.spin_limit = s.i[13] > 0 ? (unsigned)s.i[13] : 4000000u;
       a.split = (unsigned)s.i[8]; a.slots = (unsigned)s.i[11]; a.solo = (unsigned)s.i[12];
       if (s.kind == ST_XCD_RES) return launch_xcd_res(s.variant, a, s.grid, l);
       return xcd_fn(s.variant, a, s.grid);

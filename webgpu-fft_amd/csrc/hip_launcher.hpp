@@ -17,10 +17,24 @@ struct HipLauncher {
   hipError_t status = hipSuccess;
   unsigned* sticky = nullptr;  // device-wide error word raised by kernels with bounded waits (kern_xcd.hpp)
   unsigned* sticky_error_word() const { return sticky; }
+  // occupancy_query: launch_concurrent() does not launch but asks the runtime how many workgroups of that kernel (block size,
+  // dynamic LDS) one CU holds, and keeps the smallest answer: the planner's co-residency assumption is checked at plan creation
+  bool occupancy_query = false;
+  int min_blocks_per_cu = 1 << 30;
   // kernels whose workgroups synchronise with each other: same launch on hardware (the grid is sized so that every
   // workgroup is resident: one per CU); the emulation needs its blocks to run concurrently
   template <class... P, class... A>
   void launch_concurrent(void (*kernel)(P...), unsigned grid, unsigned block, unsigned smem, A&&... args) {
+    if (occupancy_query) {
+      if (status != hipSuccess) return;
+      if (smem > 48 * 1024) raise_lds_limit(reinterpret_cast<const void*>(kernel), smem, status);
+      if (status != hipSuccess) return;
+      int nb = 0;
+      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, (int)block, (size_t)smem);
+      if (e != hipSuccess) { status = e; return; }
+      if (nb < min_blocks_per_cu) min_blocks_per_cu = nb;
+      return;
+    }
     launch(kernel, grid, block, smem, static_cast<A&&>(args)...);
   }
 

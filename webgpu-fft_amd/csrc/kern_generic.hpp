@@ -93,43 +93,71 @@ struct R2cPostArgs {
   float scale;
   int shift; unsigned mask;
 };
-// Work item = (line b, chunk of 1024 consecutive k, 4 per lane): the divisions are wave-uniform (scalar), lanes walk k.
-// One lane forms BOTH X[k] and X[H-k] from the pair (Z[k], Z[H-k]), k = 0..H/2, so every Z is read once:
-//   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
+// Two adjacent bins per lane, moved as ONE 16-byte access on each of the four streams (Z ascending, Z mirrored, X ascending, X
+// mirrored): k and H-k have the same parity, so one stream of every pair starts on an odd element — the vector type below is
+// declared 8-byte aligned and the hardware splits nothing but the first and last line of a wave's 1 KiB run.  8-byte-per-lane
+// accesses moved this pass at 4.1 TB/s (profiles/r01_rocprof_r2c_2p22_kernel_stats.csv).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+// Work item = (line b, chunk of 256*U bin pairs): the divisions are wave-uniform (scalar), lanes walk k.
+// One lane forms X[k], X[k+1] and their mirrors X[H-k], X[H-k-1] from (Z[k], Z[k+1], Z[H-k-1], Z[H-k]), k = 0, 2, .. <= H/2, so every Z
+// is read once:   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
 static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs a) {
-  constexpr int U = 4;                       // k values per lane per item: 8 independent 8-byte loads in flight
-  const long long per = a.H / 2 + 1;
-  const long long chunks = (per + 256 * U - 1) / (256 * U);
+  constexpr int U = 2;                       // bin pairs per lane per item: 4 independent 16-byte loads in flight
+  const long long half = a.H / 2;            // bins 0..half are formed here (with their mirrors half..H)
+  const long long pairs = half / 2 + 1;      // pairs (0,1), (2,3), .. up to the one that holds bin `half`
+  const long long chunks = (pairs + 256 * U - 1) / (256 * U);
   const long long items = a.batch * chunks;
+  const cf w1 = a.tw_lo[1 & a.mask];         // e^{-2 pi i/N}: root of the odd bin of a pair from the even one
+  const auto split = [&](cf zk, cf zm, cf w, cf& xk, cf& xm) {
+    const cf zmc = {zm.x, -zm.y};
+    const cf e = (zk + zmc) * 0.5f;
+    const cf od = mul_neg_i((zk - zmc) * 0.5f);
+    const cf wo = cmul(w, od);
+    xk = (e + wo) * a.scale;
+    xm = (e - wo) * a.scale;
+    xm.y = -xm.y;
+  };
   for (long long it = blockIdx.x; it < items; it += gridDim.x) {
     const long long b = it / chunks;
-    const long long k0 = (it - b * chunks) * (256 * U) + threadIdx.x;
+    const long long p0 = (it - b * chunks) * (256 * U) + threadIdx.x;
     const cf* z = a.z + b * a.H;
     cf* x = a.x + b * a.x_line_stride;
-    cf zk[U], zm[U];
+    f4u za[U], zb[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const long long k = k0 + j * 256;
-      const long long kc = k < per ? k : 0;            // clamp: out-of-range lanes read bin 0 and store nothing
-      zk[j] = MI_POST_LD(z + kc);
-      zm[j] = MI_POST_LD(z + (kc == 0 ? 0 : a.H - kc));
+      const long long k = 2 * (p0 + j * 256);
+      // full pair: both bins <= half and the second one is not its own mirror; everything else (first pair's Z[H] := Z[0], the
+      // last pair of a line, lanes beyond the line) goes element by element below
+      const bool full = k > 0 && 2 * (k + 1) < a.H;
+      const long long kc = full ? k : 2;                                  // clamped lanes read somewhere harmless and in range
+      if (a.H >= 8) { za[j] = *reinterpret_cast<const f4u*>(z + kc); zb[j] = *reinterpret_cast<const f4u*>(z + (a.H - kc - 1)); }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const long long k = k0 + j * 256;
-      if (k >= per) continue;
-      const long long km = k == 0 ? 0 : a.H - k;
-      const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
-      const cf zmc = {zm[j].x, -zm[j].y};
-      const cf e = (zk[j] + zmc) * 0.5f;
-      const cf od = mul_neg_i((zk[j] - zmc) * 0.5f);
-      const cf wo = cmul(w, od);
-      const cf xk = (e + wo) * a.scale;
-      cf xm = (e - wo) * a.scale;
-      xm.y = -xm.y;
-      MI_POST_ST(x + k, xk);
-      if (k == 0) MI_POST_ST(x + a.H, xm);            // X[H] = E[0] - O[0]
-      else if (km != k) MI_POST_ST(x + km, xm);
+      const long long k = 2 * (p0 + j * 256);
+      if (k > half) continue;
+      const bool full = k > 0 && 2 * (k + 1) < a.H && a.H >= 8;
+      const cf w0 = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
+      if (full) {
+        cf x0, m0, x1, m1;
+        split(cf{za[j].x, za[j].y}, cf{zb[j].z, zb[j].w}, w0, x0, m0);                  // (Z[k],   Z[H-k])
+        split(cf{za[j].z, za[j].w}, cf{zb[j].x, zb[j].y}, cmul(w0, w1), x1, m1);        // (Z[k+1], Z[H-k-1])
+        const f4u up = {x0.x, x0.y, x1.x, x1.y}, dn = {m1.x, m1.y, m0.x, m0.y};
+        *reinterpret_cast<f4u*>(x + k) = up;
+        *reinterpret_cast<f4u*>(x + (a.H - k - 1)) = dn;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const long long kk = k + e;
+          if (kk > half) continue;
+          const long long km = kk == 0 ? 0 : a.H - kk;
+          cf xk, xm;
+          split(z[kk], z[km], e ? cmul(w0, w1) : w0, xk, xm);
+          x[kk] = xk;
+          if (kk == 0) x[a.H] = xm;                                       // X[H] = E[0] - O[0]
+          else if (km != kk) x[km] = xm;
+        }
+      }
     }
   }
 }
@@ -146,37 +174,58 @@ struct C2rPreArgs {
   int shift; unsigned mask;
 };
 static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a) {
-  constexpr int U = 4;
-  const long long per = a.H / 2 + 1;
-  const long long chunks = (per + 256 * U - 1) / (256 * U);
+  constexpr int U = 2;                       // bin pairs per lane per item, 16-byte accesses as in r2c_post_kernel
+  const long long half = a.H / 2;
+  const long long pairs = half / 2 + 1;
+  const long long chunks = (pairs + 256 * U - 1) / (256 * U);
   const long long items = a.batch * chunks;
+  const cf w1 = a.tw_lo[1 & a.mask];
+  const auto merge = [&](cf p, cf q, cf w, cf& zk, cf& zm) {
+    const cf qc = {q.x, -q.y};
+    const cf e = p + qc;
+    const cf o = cmul_conj(p - qc, w);       // * e^{+2 pi i k/N}
+    zk = e + mul_pos_i(o);
+    const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};
+    zm = ec + mul_pos_i(oc);
+  };
   for (long long it = blockIdx.x; it < items; it += gridDim.x) {
     const long long b = it / chunks;
-    const long long k0 = (it - b * chunks) * (256 * U) + threadIdx.x;
+    const long long p0 = (it - b * chunks) * (256 * U) + threadIdx.x;
     const cf* x = a.x + b * a.x_line_stride;
     cf* z = a.z + b * a.H;
-    cf xk[U], xm[U];
+    f4u xa[U], xb[U];
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const long long k = k0 + j * 256;
-      const long long kc = k < per ? k : 0;
-      xk[j] = x[kc];
-      xm[j] = x[a.H - kc];
+      const long long k = 2 * (p0 + j * 256);
+      const bool full = k > 0 && 2 * (k + 1) < a.H;
+      const long long kc = full ? k : 2;
+      if (a.H >= 8) { xa[j] = *reinterpret_cast<const f4u*>(x + kc); xb[j] = *reinterpret_cast<const f4u*>(x + (a.H - kc - 1)); }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
-      const long long k = k0 + j * 256;
-      if (k >= per) continue;
-      cf p = xk[j], q = xm[j];
-      if (k == 0) { p.y = 0.0f; q.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
-      const cf w = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
-      const cf qc = {q.x, -q.y};
-      const cf e = p + qc;
-      const cf o = cmul_conj(p - qc, w);   // * e^{+2 pi i k/N}
-      z[k] = e + mul_pos_i(o);
-      if (k != 0 && a.H - k != k) {
-        const cf ec = {e.x, -e.y}, oc = {o.x, -o.y};
-        z[a.H - k] = ec + mul_pos_i(oc);
+      const long long k = 2 * (p0 + j * 256);
+      if (k > half) continue;
+      const bool full = k > 0 && 2 * (k + 1) < a.H && a.H >= 8;
+      const cf w0 = cmul(a.tw_hi[(unsigned)k >> a.shift], a.tw_lo[(unsigned)k & a.mask]);
+      if (full) {
+        cf z0, m0, z1, m1;
+        merge(cf{xa[j].x, xa[j].y}, cf{xb[j].z, xb[j].w}, w0, z0, m0);                  // (X[k],   X[H-k])
+        merge(cf{xa[j].z, xa[j].w}, cf{xb[j].x, xb[j].y}, cmul(w0, w1), z1, m1);        // (X[k+1], X[H-k-1])
+        const f4u up = {z0.x, z0.y, z1.x, z1.y}, dn = {m1.x, m1.y, m0.x, m0.y};
+        *reinterpret_cast<f4u*>(z + k) = up;
+        *reinterpret_cast<f4u*>(z + (a.H - k - 1)) = dn;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const long long kk = k + e;
+          if (kk > half) continue;
+          cf p = x[kk], q = x[a.H - kk];
+          if (kk == 0) { p.y = 0.0f; q.y = 0.0f; }   // self-conjugate bins: imaginary parts ignored
+          cf zk, zm;
+          merge(p, q, e ? cmul(w0, w1) : w0, zk, zm);
+          z[kk] = zk;
+          if (kk != 0 && a.H - kk != kk) z[a.H - kk] = zm;
+        }
       }
     }
   }

@@ -32,6 +32,9 @@
 #ifndef MI355_NT_GLOBAL
 #define MI355_NT_GLOBAL 0
 #endif
+#ifndef MI355_LINES_PREFETCH
+#define MI355_LINES_PREFETCH 1
+#endif
 
 namespace mi355 {
 
@@ -106,6 +109,10 @@ struct LineCfg {
   static constexpr int LDS_BYTES = (DATA_ELEMS + TW_LDS_ELEMS + LO_ELEMS) * 8;
   // every line lives in one wave and only ROW maps are used: exchanges need no workgroup barrier
   static constexpr bool WAVE_LOCAL = !IN_COL && !OUT_COL && TPL <= 64 && (64 % TPL) == 0;
+  // software pipelining of the resident workgroup's tile loop: the first-stage loads of the NEXT tile are issued before the
+  // current tile is computed and stored, so the memory system always has this workgroup's reads in flight (E more complex
+  // registers per thread).  ROW kernels of 64..2048 points: their register budget allows it at the occupancy the LDS permits.
+  static constexpr bool PREFETCH = MI355_LINES_PREFETCH && !IN_COL && !OUT_COL && TWID == TWID_NONE && NSTAGES == 2 && N >= 64 && N <= 2048;
   static_assert(THREADS <= 1024, "workgroup too large");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
@@ -288,6 +295,23 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
   const bool fs_hoist = C::TWID == TWID_FOURSTEP_IN && ((long long)gridDim.x * C::T) % a.fs_group == 0;
   if constexpr (C::TWID == TWID_FOURSTEP_IN) { if (fs_hoist) fourstep_in_roots<C>(fsw, a, blockIdx.x, t); }
 
+  if constexpr (C::PREFETCH) {
+    cf v[C::E], vn[C::E];
+    long long tile = blockIdx.x;
+    if (tile < a.num_tiles) stage_read<C, 0>(v, a, tile, t, lds);
+    for (; tile < a.num_tiles; tile += gridDim.x) {
+      const long long next = tile + gridDim.x;
+      if (next < a.num_tiles) stage_read<C, 0>(vn, a, next, t, lds);      // in flight while this tile is computed and stored
+      stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, lo_lds);
+      lines_sync<C>();
+      stage_read<C, 1>(v, a, tile, t, lds);
+      lines_sync<C>();
+      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, lo_lds);
+#pragma unroll
+      for (int e = 0; e < C::E; ++e) v[e] = vn[e];
+    }
+    return;
+  }
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
     stage_read<C, 0>(v, a, tile, t, lds);

@@ -46,8 +46,10 @@ namespace mi355 {
 constexpr bool XCD_NT = MI355_XCD_NT != 0;   // nontemporal x loads / output stores in the fused kernel
 
 struct XcdCtl {                  // zeroed by a memset step before every launch
-  unsigned reg_total;
-  unsigned reg_xcd[16];
+  unsigned long long reg_packed; // registration: byte x = workgroups registered with XCC id x (x < 8).  ONE word, so that a workgroup
+                                 // that sees the grid complete has by construction also seen every per-XCD count (two counters
+                                 // updated by relaxed atomics could be observed out of step)
+  unsigned reg_pad[15];
   unsigned bar[512][16];         // one 64-byte line per group (XCC id x split): [0] A->B barrier, [1] B->A barrier (one-slot mode)
 };
 
@@ -137,19 +139,25 @@ MI_DEV bool xcd_wait(unsigned* counter, unsigned target, unsigned spin_limit, un
 MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, unsigned* sticky, unsigned* s_words) {
   if (threadIdx.x == 0) {
     const unsigned x = MI_XCC_ID() & 15u;
-    const unsigned r = MI_ATOMIC_ADD_U32(&ctl->reg_xcd[x], 1u);
-    MI_ATOMIC_ADD_U32(&ctl->reg_total, 1u);
-    unsigned ok = 0;
-    for (unsigned it = 0; it < spin_limit; ++it) {
-      if (MI_ATOMIC_LOAD_U32(&ctl->reg_total) >= gridDim.x) { ok = 1; break; }
-      MI_SLEEP();
+    unsigned ok = 0, r = 0;
+    unsigned long long snap = 0;
+    if (x < 8u) {   // gfx950 has 8 XCDs; anything else is reported, never mis-grouped
+      const unsigned long long old = MI_ATOMIC_ADD_U64(&ctl->reg_packed, 1ull << (8u * x));
+      r = (unsigned)(old >> (8u * x)) & 0xffu;
+      for (unsigned it = 0; it < spin_limit; ++it) {
+        snap = MI_ATOMIC_LOAD_U64(&ctl->reg_packed);
+        unsigned total = 0;
+        for (unsigned k = 0; k < 8; ++k) total += (unsigned)(snap >> (8u * k)) & 0xffu;
+        if (total >= gridDim.x) { ok = 1; break; }
+        MI_SLEEP();
+      }
     }
     // an XCD's workgroups may be split into up to 8 groups by rank (each with its own workspace slots and barrier counter):
     // smaller groups run out of phase with each other inside one XCD at the price of sharing its L2
     const unsigned split = split_arg ? split_arg : 1u;
     unsigned groups = 0, gi = 0, mine = 0, sub = 0, gsz = 0;
-    for (unsigned k = 0; k < 16; ++k) {
-      const unsigned cnt = MI_ATOMIC_LOAD_U32(&ctl->reg_xcd[k]);
+    for (unsigned k = 0; k < 8; ++k) {
+      const unsigned cnt = (unsigned)(snap >> (8u * k)) & 0xffu;
       if (!cnt) continue;
       const unsigned per = (cnt + split - 1u) / split, nsub = (cnt + per - 1u) / per;
       if (k == x) {

@@ -84,7 +84,7 @@ struct XcdResCfg {
   static constexpr int LPAD = 17;                               // pass A LDS image [1024 idx][17]: both thread maps conflict-free
   static constexpr int DATA_ELEMS = 1024 * LPAD;                // 136 KB; the pass B transpose [16 p][32 j][32 rows] (128 KB) re-uses it
   static constexpr int TW_ELEMS = 31 * 32;                      // W1024^(q k), rows q = 1..31
-  static constexpr int WORDS = 32;                              // registration words, per-wave flags, channel meeting counters
+  static constexpr int WORDS = 48;                              // registration words, per-wave flags, channel meeting counters, [32..47] phase stamps (diagnostic build)
   static constexpr int LDS_BYTES = (DATA_ELEMS + TW_ELEMS) * 8 + WORDS * 4;
   static constexpr long long CHANNEL_ELEMS = 32ll * 32 * 4 * 32;   // one channel: [consumer 32][producer 32][4 columns][32 rows] = 1 MiB
   static constexpr long long XCD_W_ELEMS = 4 * CHANNEL_ELEMS;      // exchange buffer per XCD
@@ -137,10 +137,20 @@ MI_DEV void res_fourstep(cf (&w)[32], const XcdFusedArgs& f, unsigned n2, unsign
   }
 }
 
+// STAMP (diagnostic build only, never the product variant): thread 0 of every workgroup accumulates the wall time (s_memrealtime,
+// 100 MHz) between phase boundaries into ctl->bar[256 + blockIdx][phase]; tools/res_stamps.py prints the breakdown.  The stamps go
+// to memory nothing else reads.
+#ifndef MI355_HOST_EMU
+#define MI_REALTIME() __builtin_amdgcn_s_memrealtime()
+#else
+#define MI_REALTIME() 0ull
+#endif
+#define RES_STAMP(i) do { if constexpr (STAMP) { if (t == 0) { const unsigned long long now_ = MI_REALTIME(); s_words[32 + (i)] += (unsigned)(now_ - stamp_last); stamp_last = now_; } } } while (0)
+
 // INV: inverse transform by the swap trick (re/im exchanged at the x loads and at the output stores).
 // MATH = false: the data movement and synchronisation skeleton alone (butterflies and roots skipped) — tools/microbench/xcd3.hip
 // times it to show what the FFT arithmetic costs on top.
-template <bool INV, bool MATH = true>
+template <bool INV, bool MATH = true, bool STAMP = false>
 __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const XcdFusedArgs f) {
   using K = XcdResCfg;
   MI_SMEM_DECL(smem);
@@ -149,7 +159,8 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
   unsigned* s_words = reinterpret_cast<unsigned*>(tw + K::TW_ELEMS);   // [0..6] registration, [8..15] per-wave flags, [16..19] PUSH meeting, [20..23] READ meeting, [24] abort
   const int t = threadIdx.x, lane = t & 63, wave = (int)MI_UNIFORM_U32(t >> 6);
   for (int i = t; i < K::TW_ELEMS; i += K::THREADS) tw[i] = f.tw_a[i];
-  if (t < 16) s_words[16 + t] = 0u;
+  if (t < 32) s_words[16 + t] = 0u;
+  unsigned long long stamp_last = 0;
   if (!xcd_register(f.ctl, 1u, f.spin_limit, f.sticky_error, s_words)) return;
   // wave-uniform by construction: keeping them in SGPRs lets every global access below take the "uniform base + 32-bit lane
   // offset" form (one VGPR of address per access pattern instead of a 64-bit pointer per element)
@@ -176,6 +187,7 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
   unsigned* const m_read = &s_words[20 + ch];
 
   unsigned k = 0;
+  if constexpr (STAMP) stamp_last = MI_REALTIME();
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
     cf zlo[16], zhi[16];                             // Z0: p < 16 half until it is parked, p >= 16 half until half B
 #pragma unroll 1
@@ -188,6 +200,7 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
 #pragma unroll
         for (int q = 0; q < 32; ++q) v[q] = cswap_if<INV>(ld_stream<true>(sgpr_base(xt + ((unsigned)q << 15)) + vo));
         if constexpr (MATH) fft_radix<32>(v);
+        RES_STAMP(0);                                // x loads issued, data arrived (first use), first radix-32
         if (h == 1 || k > 0) __syncthreads();        // the LDS image is free: everyone is past its last reads of it
 #pragma unroll
         for (int p = 0; p < 32; ++p) lds[(32 * a_u + p) * K::LPAD + a_cc] = v[p];
@@ -207,10 +220,12 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
           fft_radix<32>(v);
           res_fourstep(v, f, (unsigned)(32 * (int)r + 16 * h + b_c2), (unsigned)b_u2);
         }
+        RES_STAMP(1);                                // LDS exchange of the column FFT, second radix-32, four-step roots
       }
       // ---- exchange of tile set h: v[q] = Y'[k1 = b_u2 + 32 q][this column] goes to workgroup q ----
       const unsigned use = (2u * k + (unsigned)h) * uses_per_set + (unsigned)ch / depth;   // how often this buffer has been used before
       if (use > 0 && !res_wait(c_read, 32u * use, f, s_flag, s_abort, lane)) return;        // the previous payload has been read by everyone
+      RES_STAMP(2);                                  // wait: channel buffer free
       {
         cf* const pw = f.wslots + (w_off + r * 128u);                      // uniform
         const unsigned vo = (unsigned)(jj * 32 + b_u2);
@@ -218,7 +233,9 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
         for (int q = 0; q < 32; ++q) *(sgpr_base(pw + (unsigned)q * 4096u) + vo) = v[q];             // [consumer q][producer r][jj][row]
       }
       res_signal(c_push, m_push, lane);
+      RES_STAMP(3);                                  // push stores issued and complete (vmcnt(0): also drains older output stores)
       if (!res_wait(c_push, 32u * (use + 1u), f, s_flag, s_abort, lane)) return;
+      RES_STAMP(4);                                  // wait: everyone has pushed
       {
         const cf* const pr = f.wslots + (w_off + r * 4096u);               // uniform
         const unsigned vo = (unsigned)(jj * 32 + row);
@@ -226,6 +243,7 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
         for (int q = 0; q < 32; ++q) v[q] = ld_sc1(sgpr_base(pr + (unsigned)q * 128u) + vo);          // [consumer r][producer q][jj][row]
       }
       res_signal(c_read, m_read, lane);
+      RES_STAMP(5);                                  // payload read from the L2
       // ---- pass B stage 0 on the butterfly (k1 = 32 r + row, j = 16 h + b_c2) ----
       if constexpr (MATH) {
         fft_radix<32>(v);
@@ -240,6 +258,7 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
           }
         }
       }
+      RES_STAMP(6);                                  // pass B stage 0
       if (h == 0) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) { zlo[p] = v[p]; zhi[p] = v[16 + p]; }
@@ -272,7 +291,15 @@ __global__ void __launch_bounds__(XcdResCfg::THREADS) fft_xcd_res_kernel(const X
         if constexpr (MATH) fft_radix<32>(y);
 #pragma unroll
         for (int s = 0; s < 32; ++s) st_stream<true>(sgpr_base(ot + (16u << 10) + ((unsigned)s << 15)) + vo, cswap_if<INV>(y[s] * f.scale));   // p = 16 + b_c2
+        RES_STAMP(7);                                // LDS transposes, pass B stage 1, output stores issued
       }
+    }
+  }
+  if constexpr (STAMP) {
+    if (t == 0) {
+      for (int i = 0; i < 8; ++i) f.ctl->bar[256 + blockIdx.x][i] = s_words[32 + i];
+      f.ctl->bar[256 + blockIdx.x][8] = k;
+      f.ctl->bar[256 + blockIdx.x][9] = gslot * 32u + r;
     }
   }
 }

@@ -137,6 +137,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= 0) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_SPIN_LIMIT")) { const long long v = std::atoll(s); if (v >= 1 && v <= 0x7fffffffll) o.xcd_spin_limit = (unsigned)v; }
   if (const char* s = std::getenv("MI355FFT_XCD_RES_DEPTH")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_res_depth = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 32) o.xcd_split = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
@@ -206,6 +207,9 @@ struct Builder {
     const int64_t cap = (int64_t)opt.compute_units * 16;
     return (unsigned)std::max<int64_t>(1, std::min(blocks, cap));
   }
+  // streaming kernels whose work items are independent chunks: one short-lived workgroup per item.  One-shot grids stream at
+  // 6.2-6.5 TB/s on this chip where resident grid-stride loops reach 5.3-5.5 (profiles/r02_copy_ceiling.log)
+  unsigned oneshot_grid(int64_t items) const { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)1 << 30)); }
   Step& push(StepKind k) { ir.steps.emplace_back(); ir.steps.back().kind = k; return ir.steps.back(); }
 
   // stage tables of a line kernel: stage 1 [R1-1][R0] roots of order R0*R1, stage 2 [R2-1][R0*R1] of order N
@@ -264,6 +268,7 @@ struct Builder {
     const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, false, false, false, 0);
     const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10);
+    if (!solo && !opt.xcd_shared) return false;
     int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
     PtrRef wslots, ctl;
     if (solo) {
@@ -285,7 +290,7 @@ struct Builder {
     st.variant = xm->id;
     st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
     st.i[0] = planes; st.i[1] = N; st.i[2] = 0; st.i[3] = 0; st.i[9] = N; st.i[10] = N;
-    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tone.off; st.i[7] = tone.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tone.off; st.i[7] = tone.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0; st.i[13] = opt.xcd_spin_limit;
     st.f[0] = scale;
     st.grid = (unsigned)grid;
     ir.route += std::string(solo ? "xcd-2d-solo[" : "xcd-2d[") + std::to_string(N0) + "x" + std::to_string(N1) + "] ";
@@ -305,6 +310,7 @@ struct Builder {
     const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
     // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
     const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / 2 && opt.xcd_fused != 2;
+    if (!solo && !opt.xcd_shared) return false;
     int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
     PtrRef wslots, ctl;
     if (solo) {
@@ -329,7 +335,7 @@ struct Builder {
     st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
     st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1;
     st.i[9] = c2r ? N / 2 + 1 : N / 2; st.i[10] = c2r ? N / 2 : N / 2 + 1;        // pitches in complex elements
-    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0; st.i[13] = opt.xcd_spin_limit;
     st.f[0] = scale;
     if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;   // as emit_axis: two co-resident workgroups per CU
     st.grid = (unsigned)grid;
@@ -375,7 +381,7 @@ struct Builder {
     st.p[0] = z; st.p[1] = out;
     split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
+    st.grid = oneshot_grid(lines * ((H / 4 + 1 + 511) / 512));      // items of 512 bin pairs (r2c_post_kernel)
     ir.route += "r2c-split ";
     return MI355FFT_OK;
   }
@@ -389,7 +395,7 @@ struct Builder {
     st.p[0] = packed; st.p[1] = z;
     split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = generic_grid(lines * (((H / 2 + 1) + 1023) / 1024) * 256);
+    st.grid = oneshot_grid(lines * ((H / 4 + 1 + 511) / 512));      // items of 512 bin pairs (c2r_pre_kernel)
     // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
     int rc = emit_axis(z, out, H, 1, lines, true, scale, err);
     if (rc) return rc;
@@ -438,7 +444,10 @@ struct Builder {
         return MI355FFT_OK;
       }
     }
-    if (!opt.force_generic && S > 1 && p2) {
+    // the column line kernels address a tile with 32-bit element offsets (kern_lines.hpp: voff = idx * S): a strided axis whose
+    // plane spans 2^32 elements or more (32 GiB of complex data) stays on the stage route, which indexes with 64 bits
+    const bool col_span_ok = (uint64_t)N * (uint64_t)S < (1ull << 32);
+    if (!opt.force_generic && S > 1 && p2 && col_span_ok) {
       // an axis with stride S > 1 (N-D transforms): T adjacent lines form a column tile
       const LineKernelMeta* m = find_line_kernel((int)N, true, true, inverse, inverse, 0);
       if (m && S % m->T == 0) {
@@ -466,7 +475,7 @@ struct Builder {
         return MI355FFT_OK;
       }
     }
-    if (!opt.force_generic && S == 1 && N == (1 << 20) && opt.xcd_res && !opt.only_pass && opt.compute_units % 32 == 0) {
+    if (!opt.force_generic && S == 1 && N == (1 << 20) && opt.xcd_res && opt.xcd_shared && !opt.only_pass && opt.compute_units % 32 == 0) {
       // XCD-resident route (kern_xcd_res.hpp): the transform stays in the registers and LDS of one XCD's 32 workgroups between
       // its passes; hand-offs go through a 4 MiB L2-resident exchange buffer per XCD.  One workgroup per CU, all co-resident.
       const int shift = 10;
@@ -479,13 +488,13 @@ struct Builder {
       const PtrRef ctl = alloc_work(40960);
       { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
       Step& st = push(ST_XCD_RES);
-      st.variant = (inverse ? 1 : 0) + (opt.xcd_res == 2 ? 2 : 0);
+      st.variant = (inverse ? 1 : 0) + (opt.xcd_res == 2 || opt.xcd_res == 4 ? 2 : 0) + (opt.xcd_res >= 3 && !inverse ? 4 : 0);   // 3: stamps, 4: stamps on the skeleton
       st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
       st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N; st.i[10] = N;
-      st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = opt.xcd_res_depth; st.i[11] = 1; st.i[12] = 0;
+      st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = opt.xcd_res_depth; st.i[11] = 1; st.i[12] = 0; st.i[13] = opt.xcd_spin_limit;
       st.f[0] = scale;
       st.grid = (unsigned)opt.compute_units;
-      ir.route += "xcd-resident[N=1024x1024,depth=" + std::to_string(opt.xcd_res_depth) + (opt.xcd_res == 2 ? ",skeleton" : "") + "] ";
+      ir.route += "xcd-resident[N=1024x1024,depth=" + std::to_string(opt.xcd_res_depth) + (opt.xcd_res == 2 || opt.xcd_res == 4 ? ",skeleton" : "") + (opt.xcd_res >= 3 ? ",stamps" : "") + "] ";
       return MI355FFT_OK;
     }
     if (!opt.force_generic && S == 1 && p2 && N >= 4096 && opt.xcd_fused && !opt.only_pass) {
@@ -494,7 +503,8 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry()) if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
-      if (xm && (N > 4096 || opt.xcd_fused == 2)) {
+      if (xm && (N > 4096 || opt.xcd_fused == 2) &&
+          (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
         const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
         const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
         // transforms of at most 1 MiB: every workgroup walks whole transforms alone ("solo": no registration, no cross-
@@ -524,7 +534,7 @@ struct Builder {
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
         st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N; st.i[10] = N;
-        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0;
+        st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0; st.i[13] = opt.xcd_spin_limit;
         st.f[0] = scale;
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
         if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;

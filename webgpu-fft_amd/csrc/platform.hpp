@@ -23,6 +23,8 @@
 #define MI_XCC_ID() (__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) & 0xf)
 #define MI_ATOMIC_ADD_U32(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MI_ATOMIC_LOAD_U32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MI_ATOMIC_ADD_U64(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MI_ATOMIC_LOAD_U64(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MI_ATOMIC_OR_U32(p, v) __hip_atomic_fetch_or((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MI_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define MI_ACQUIRE_AGENT() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
@@ -56,6 +58,8 @@ void yield_thread();
 #define MI_XCC_ID() (emu::t_blockIdx.x % emu::g_xcds)
 #define MI_ATOMIC_ADD_U32(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
 #define MI_ATOMIC_LOAD_U32(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
+#define MI_ATOMIC_ADD_U64(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
+#define MI_ATOMIC_LOAD_U64(p) __atomic_load_n((p), __ATOMIC_SEQ_CST)
 #define MI_ATOMIC_OR_U32(p, v) __atomic_fetch_or((p), (v), __ATOMIC_SEQ_CST)
 #define MI_WAIT_VMEM() do { } while (0)
 #define MI_ACQUIRE_AGENT() __atomic_thread_fence(__ATOMIC_SEQ_CST)

@@ -14,7 +14,9 @@ function unwrapBuffer(x, what) {
   if (x instanceof HipBuffer) return { buf: x, offset: 0 };
   if (x instanceof BufferView) {
     if (x.segments.length !== 1) throw new Error("Unsupported: " + what + " BufferView with more than one segment");
-    return { buf: x.segments[0].buffer, offset: x.segments[0].offsetBytes };
+    if (!(x.segments[0].buffer instanceof HipBuffer)) throw new Error(what + " BufferView segment must be a buffer created by this device");
+    if (x.logicalByteOffset + x.lengthBytes > x.segments[0].sizeBytes) throw new Error(what + " BufferView range exceeds its segment");
+    return { buf: x.segments[0].buffer, offset: x.segments[0].offsetBytes + x.logicalByteOffset };
   }
   throw new Error(what + " must be a buffer created by this device (or a single-segment BufferView)");
 }
@@ -57,7 +59,9 @@ export class Plan extends NativePlanBase {
     return native.planWorkspaceBytes(this._h);
   }
 
-  _prepareKernel(kernel) {
+  // commandEncoder: kernels given as an array of GPU buffers / BufferViews ("array-sources", fftconv.js:920-941) are packed by
+  // one copyBufferToBuffer per kernel recorded ahead of the plan's own launches
+  _prepareKernel(kernel, commandEncoder) {
     const single = 2 * prod(this.kernelShape);
     const packed = single * this.kernelCount;
     let payload = null;
@@ -79,18 +83,32 @@ export class Plan extends NativePlanBase {
       } else if (kernel.some((k) => k instanceof Float32Array)) {
         throw new Error("kernel array items must be all Float32Array or all GPUBuffer/BufferView values");
       } else {
-        throw new Error("Unsupported: kernel as an array of GPU buffers (pack the kernels into one buffer)");
+        const bytesEach = single * 4;
+        const srcs = kernel.map((k, i) => {
+          const u = unwrapBuffer(k, "kernel[" + i + "]");
+          const have = (k instanceof BufferView ? k.lengthBytes : u.buf.size - u.offset);
+          if (have < bytesEach) throw new Error("kernel[" + i + "] is too small: need " + bytesEach + " bytes, have " + have);
+          return u;
+        });
+        this._ensureKernelUpload(packed * 4);
+        for (let i = 0; i < this.kernelCount; i++) {
+          native.encoderCopyBuffer(commandEncoder._h, srcs[i].buf._h, srcs[i].offset, this._kernelUpload._h, i * bytesEach, bytesEach);
+        }
+        return { buf: this._kernelUpload, offset: 0 };
       }
     } else {
       return unwrapBuffer(kernel, "kernel");
     }
-    const bytes = packed * 4;
+    this._ensureKernelUpload(packed * 4);
+    this.device.queue.writeBuffer(this._kernelUpload, 0, payload);
+    return { buf: this._kernelUpload, offset: 0 };
+  }
+
+  _ensureKernelUpload(bytes) {
     if (!this._kernelUpload || this._kernelUpload.size < bytes) {
       if (this._kernelUpload) this._kernelUpload.destroy();
       this._kernelUpload = this.device.createBuffer({ size: bytes, usage: 0 });
     }
-    this.device.queue.writeBuffer(this._kernelUpload, 0, payload);
-    return { buf: this._kernelUpload, offset: 0 };
   }
 
   exec(commandEncoder, execOpts) {
@@ -113,7 +131,7 @@ export class Plan extends NativePlanBase {
     }
     if (this.type === "fftconv") {
       if (o.kernel == null) throw new Error("fftconv exec requires kernel");
-      const k = this._prepareKernel(o.kernel);
+      const k = this._prepareKernel(o.kernel, commandEncoder);
       args.kernel = k.buf._h;
       args.kernelOffsetBytes = k.offset;
     }

@@ -200,6 +200,38 @@ test("fftconv channelPolicy maps multi-kernel outputs into channel lanes (N=12,b
   plan.destroy(); inBuf.destroy(); outBuf.destroy();
 });
 
+test("fftconv kernels as an array of GPU buffers / BufferViews (array-sources, fftconv.js:920-941) and BufferView input", async () => {
+  const dev = await ensureDevice();
+  const n = 64, batch = 3, K = 3;
+  const x = orc.randomComplexInterleaved(n * batch, orc.mulberry32(777));
+  const kern = [0, 1, 2].map((k) => orc.randomComplexInterleaved(n, orc.mulberry32(900 + k)));
+  // kernel 0: its own buffer; kernel 1: a BufferView into the middle of a larger buffer; kernel 2: a view with a logical offset
+  const k0 = fft.uploadComplex(dev, kern[0]);
+  const big = dev.createBuffer({ size: 4 * n * 8, usage: 0 });
+  dev.queue.writeBuffer(big, n * 8, kern[1]);
+  dev.queue.writeBuffer(big, 3 * n * 8, kern[2]);
+  const k1 = fft.BufferView.fromBuffer(big, n * 8, n * 8);
+  const k2 = new fft.BufferView({ segments: [{ buffer: big, offsetBytes: 2 * n * 8, sizeBytes: 2 * n * 8 }], logicalByteOffset: n * 8, lengthBytes: n * 8 });
+  // the data sits behind a 128-byte prefix of a larger buffer and is passed as a view
+  const pre = 16;
+  const inPhys = new Float32Array(2 * (pre + n * batch)).fill(3.0);
+  inPhys.set(x, 2 * pre);
+  const inBuf = fft.uploadComplex(dev, inPhys);
+  const outBuf = dev.createBuffer({ size: K * batch * n * 8, usage: 0 });
+  const plan = fft.createPlan(dev, { type: "fftconv", shape: [n], batch, fftConv: { mode: "convolution", boundary: "circular", kernelCount: K } });
+  const enc = dev.createCommandEncoder();
+  plan.exec(enc, { input: fft.BufferView.fromBuffer(inBuf, pre * 8), output: outBuf, kernel: [k0, k1, k2] });
+  dev.queue.submit([enc.finish()]);
+  const got = await fft.downloadComplex(dev, outBuf, K * batch * n);
+  const want = new Float32Array(2 * K * batch * n);
+  for (let k = 0; k < K; k++) want.set(orc.fftConvRef({ input: x, kernel: kern[k], shape: [n], batch, mode: "convolution" }), 2 * k * batch * n);
+  orc.assertCloseArray(got, want, 5e-3, 5e-3, "fftconv array-sources");
+  assert(orc.relL2(got, want) < TOL, "fftconv array-sources rel_l2");
+  assertThrows(() => plan.exec(dev.createCommandEncoder(), { input: inBuf, output: outBuf, kernel: [k0, kern[1], k2] }), /all Float32Array or all GPUBuffer/);
+  assertThrows(() => plan.exec(dev.createCommandEncoder(), { input: inBuf, output: outBuf, kernel: [k0, fft.BufferView.fromBuffer(big, 0, 8), k2] }), /too small/);
+  plan.destroy(); inBuf.destroy(); outBuf.destroy(); k0.destroy(); big.destroy();
+});
+
 test("fftconv BASELINE config 4 (README preset: shape=[256] batch=4, 64ch -> 128ch, 3 kernels) vs reference fixture", async () => {
   const dev = await ensureDevice();
   const c = cases.fftconv_cfg4_N256_b4_k3;

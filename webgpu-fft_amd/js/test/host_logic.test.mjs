@@ -127,11 +127,22 @@ test("addon exports every entry point and has no CPU fallback", () => {
   if (!fs.existsSync("/dev/kfd")) assertThrows(() => fft.openDevice(), /HIP|ROCm|device/, "openDevice without a GPU");
 });
 
-test("BufferView accepts single segments and validates ranges", () => {
+test("BufferView has the reference's constructor, fromBuffer and validation (src/utils/buffer_view.js:18-41)", () => {
   const fake = { size: 64, destroy() {} };
-  const v = fft.BufferView.from(fake, 8, 32);
-  assert(v.size === 32 && v.segments.length === 1);
-  assertThrows(() => new fft.BufferView([{ buffer: fake, offsetBytes: 60, sizeBytes: 16 }]), /outside its buffer/);
+  const v = new fft.BufferView({ segments: [{ buffer: fake, offsetBytes: 8, sizeBytes: 32 }], logicalByteOffset: 8, lengthBytes: 16 });
+  assert(v.segments.length === 1 && v.logicalByteOffset === 8 && v.lengthBytes === 16);
+  const w = fft.BufferView.fromBuffer(fake, 16);
+  assert(w.lengthBytes === 48 && w.logicalByteOffset === 0 && w.segments[0].offsetBytes === 16 && w.segments[0].sizeBytes === 48);
+  assert(fft.BufferView.fromBuffer(fake).lengthBytes === 64);
+  assertThrows(() => new fft.BufferView({ segments: [], lengthBytes: 8 }), /segments must be a non-empty array/);
+  assertThrows(() => new fft.BufferView({ segments: [{ buffer: fake, offsetBytes: 0, sizeBytes: 8 }], logicalByteOffset: -1, lengthBytes: 8 }), /logicalByteOffset must be a non-negative integer/);
+  assertThrows(() => new fft.BufferView({ segments: [{ buffer: fake, offsetBytes: 0, sizeBytes: 8 }] }), /lengthBytes must be a positive integer/);
+  assertThrows(() => new fft.BufferView({ segments: [{ offsetBytes: 0, sizeBytes: 8 }], lengthBytes: 8 }), /segment missing buffer/);
+  assertThrows(() => new fft.BufferView({ segments: [{ buffer: fake, offsetBytes: 60, sizeBytes: 16 }], lengthBytes: 16 }), /segment out of bounds: offsetBytes\+sizeBytes=76 > buffer.size=64/);
+  // round-1 spellings stay as aliases
+  const a = fft.BufferView.from(fake, 8, 32);
+  assert(a.size === 32 && a.lengthBytes === 32 && a.segments.length === 1);
+  assert(new fft.BufferView([{ buffer: fake, offsetBytes: 8 }]).lengthBytes === 56);
 });
 
 run();
