@@ -134,7 +134,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
-  if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= 0) o.lines_tiles_per_wg = v; }
+  if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= -1) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPIN_LIMIT")) { const long long v = std::atoll(s); if (v >= 1 && v <= 0x7fffffffll) o.xcd_spin_limit = (unsigned)v; }
@@ -236,14 +236,19 @@ struct Builder {
     st.p[2] = plo; st.p[3] = phi; st.i[3] = 10; st.i[4] = 1023;
   }
 
-  unsigned lines_grid(const LineKernelMeta& m, int64_t tiles) const {
+  unsigned lines_grid(const LineKernelMeta& m, int64_t tiles, bool plain_c2c = false) const {
     int64_t per_cu = 8;
     if (m.lds_bytes > 0) per_cu = std::min<int64_t>(per_cu, (160 * 1024) / m.lds_bytes);
     per_cu = std::min<int64_t>(per_cu, 2048 / m.threads);
     per_cu = std::max<int64_t>(per_cu, 1);
     // lines_tiles_per_wg > 0: a short-lived workgroup per `lines_tiles_per_wg` tiles instead of a resident grid walking the batch
     // (one-shot grids stream at 6.2-6.5 TB/s where persistent loops reach 5.3-5.5: profiles/r02_copy_ceiling.log)
-    if (opt.lines_tiles_per_wg > 0) return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + opt.lines_tiles_per_wg - 1) / opt.lines_tiles_per_wg, (int64_t)1 << 30));
+    // default (0): ROW kernels of up to 1024 points take one tile per workgroup (measured +10...+14 % at N = 64..512, +6 % at 1024:
+    // profiles/r02_oneshot_grids.log); longer lines would re-stage tables of a quarter of a tile or more per workgroup and the
+    // PASS kernels hoist per-launch state, so they stay resident.  -1 keeps every line kernel resident.
+    int tpw = opt.lines_tiles_per_wg;
+    if (tpw == 0 && plain_c2c && !m.in_col && !m.out_col && m.twid == 0 && m.N <= 1024) tpw = 1;   // (the r2c / c2r / product variants measured better resident)
+    if (tpw > 0) return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + tpw - 1) / tpw, (int64_t)1 << 30));
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, per_cu * opt.compute_units));
   }
 
@@ -415,7 +420,7 @@ struct Builder {
     const int64_t tiles = (lines + m->T - 1) / m->T;
     st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = in_pitch; st.i[4] = 1; st.i[5] = out_pitch;
     st.f[0] = scale;
-    st.grid = lines_grid(*m, tiles);
+    st.grid = lines_grid(*m, tiles, true);
     ir.route += "lines[N=" + std::to_string(N) + ",pitch=" + std::to_string(in_pitch) + "/" + std::to_string(out_pitch) + "] ";
     return true;
   }
@@ -439,7 +444,7 @@ struct Builder {
         const int64_t tiles = (lines + m->T - 1) / m->T;
         st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = N; st.i[4] = 1; st.i[5] = N;
         st.f[0] = scale;
-        st.grid = lines_grid(*m, tiles);
+        st.grid = lines_grid(*m, tiles, true);
         ir.route += "lines[N=" + std::to_string(N) + "] ";
         return MI355FFT_OK;
       }
