@@ -257,7 +257,7 @@ def main():
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r|fftconv|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
-        nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)+\d+)_b(\d+)", args.workload)      # N-D: axis 0 first
+        nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)+\d+)_b(\d+)(_view)?", args.workload)      # N-D: axis 0 first; _view: padded read + cropped write
         if nd:
             ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
             tot = 1
@@ -278,6 +278,18 @@ def main():
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n
         opts = {"type": "c2c", "shape": list(ND_SHAPE) if ND_SHAPE else [n], "batch": batch, "direction": "forward", "normalize": "none"}
+        if args.workload.endswith("_view"):
+            # probe of the sides fused into the line kernels: the input is a smaller array padded into the
+            # logical domain on read (centred), the output a cropped window, with a zero range on each side
+            vshape = [max(1, (v * 15) // 16) for v in opts["shape"]]
+            opts["ioView"] = {"input": {"shape": vshape, "placement": "center"}, "output": {"shape": vshape, "placement": "center"}}
+            opts["zeroPad"] = {"read": {"start": [1] * len(vshape), "end": [v - 1 for v in opts["shape"]]},
+                               "write": {"start": [0] * len(vshape), "end": [v - 2 for v in opts["shape"]]}}
+            vn = 1
+            for v in vshape:
+                vn *= v
+            in_bytes = out_bytes = vn * batch * 8
+            in_row_floats = 2 * vn
     elif typ == "fftconv":   # circular convolution with one full-length kernel (probe): forward FFTs, product, inverse FFT
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n

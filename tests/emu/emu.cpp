@@ -144,6 +144,7 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   opt.compute_units = std::getenv("MI355_EMU_CUS") ? std::atoi(std::getenv("MI355_EMU_CUS")) : 2;
   if (const char* e = std::getenv("MI355_EMU_XCD_FUSED")) opt.xcd_fused = std::atoi(e); else opt.xcd_fused = 0;
   if (const char* e = std::getenv("MI355_EMU_XCD_SPLIT")) opt.xcd_split = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_FUSE_VIEWS")) opt.fuse_views = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_RES")) opt.xcd_res = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_RES_DEPTH")) opt.xcd_res_depth = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_SLOTS")) opt.xcd_slots = std::atoi(e);

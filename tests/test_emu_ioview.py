@@ -94,6 +94,85 @@ def test_c2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
     assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, route
 
 
+FUSED_CASES = [
+    # power-of-two axes: every side feature rides the first load / last store of the line kernels (no staging launch at all)
+    ([64], {"input": {"shape": [40], "placement": "center"}, "output": {"shape": [48], "offset": [5]}}, {"read": {"start": [4], "end": [60]}, "write": {"start": [2], "end": [62]}}, None),
+    ([16], {"output": {"shape": [24], "placement": "center", "clearOutside": True}}, None, None),
+    ([64, 16], {"input": {"shape": [50, 12], "offset": [3, 2]}, "output": {"shape": [70, 10], "offset": [-2, 4]}}, {"write": {"start": [1, 0], "end": [63, 15]}}, None),
+    ([32, 8, 4], {"input": {"shape": [20, 8, 3]}}, {"read": {"start": [0, 1, 0], "end": [32, 7, 4]}}, None),
+    ([128, 4], None, {"read": {"start": [8, 0], "end": [120, 3]}, "write": {"start": [0, 1], "end": [128, 4]}}, None),
+    # strided physical layouts on both sides (padded rows, permuted batch pitch) together with views
+    ([32, 16], {"input": {"shape": [24, 16]}}, None, {"input": {"strides": [1, 40], "offsetElements": 7, "batchStrideElements": 700},
+                                                      "output": {"strides": [2, 70], "offsetElements": 3, "batchStrideElements": 1200}}),
+]
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("shape,io_view,zero_pad,layouts", FUSED_CASES)
+def test_c2c_sides_fused_into_the_line_kernels(oracle, monkeypatch, shape, io_view, zero_pad, layouts, fuse):
+    """with power-of-two axes the strided layout / ioView / zeroPad of each side is the address map of the
+    first / last line-kernel launch (route: only *-mapped[...] launches); MI355_EMU_FUSE_VIEWS=0 is the staging route
+    (gather / embed / zero / extract / scatter passes) — both against the numpy restatement of the reference semantics"""
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fuse))
+    batch = 3
+    rank = len(shape)
+    for direction in ("forward", "inverse"):
+        opts = {"type": "c2c", "shape": shape, "batch": batch, "direction": direction, "normalize": "backward"}
+        if io_view:
+            opts["ioView"] = io_view
+        if zero_pad:
+            opts["zeroPad"] = zero_pad
+        if layouts:
+            opts["layout"] = {"interleavedComplex": True}
+            for side, lay in layouts.items():
+                opts["layout"][side + "Strides"] = lay["strides"]
+                opts["layout"][side + "OffsetElements"] = lay["offsetElements"]
+                opts["layout"][side + "BatchStrideElements"] = lay["batchStrideElements"]
+        desc, r = _desc(opts)
+        in_shape = r["io_view"]["input"]["shape"] if r["io_view"]["input"] else shape
+        out_shape = r["io_view"]["output"]["shape"] if r["io_view"]["output"] else shape
+        li, lo = (layouts or {}).get("input"), (layouts or {}).get("output")
+
+        def extent(lay, shp):
+            if not lay:
+                return int(np.prod(shp)) * batch
+            return lay["offsetElements"] + (batch - 1) * lay["batchStrideElements"] + sum((shp[d] - 1) * lay["strides"][d] for d in range(rank)) + 1
+
+        def to_dense(phys, lay, shp):          # physical buffer -> dense [batch][shape] view contents
+            if not lay:
+                return phys.copy()
+            dense = np.zeros((batch, *reversed(shp), 2), np.float32)
+            p2 = phys.reshape(-1, 2)
+            for bi in range(batch):
+                for idx in np.ndindex(*reversed(shp)):
+                    c = idx[::-1]
+                    dense[(bi, *idx)] = p2[lay["offsetElements"] + bi * lay["batchStrideElements"] + sum(c[d] * lay["strides"][d] for d in range(rank))]
+            return dense.reshape(-1)
+
+        xin = oracle.random_complex_interleaved(extent(li, in_shape), 4242 + sum(shape))
+        out_floats = 2 * extent(lo, out_shape)
+        sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
+        got, route, launches = emu.run_plan(desc, xin, out_floats, out_init=sentinel)
+        want_dense = reference(oracle, to_dense(xin, li, in_shape), shape, batch, direction, "backward", r["io_view"]["input"], r["io_view"]["output"],
+                               r["zero_pad"]["read"], r["zero_pad"]["write"], to_dense(sentinel, lo, out_shape))
+        got_dense = to_dense(got, lo, out_shape)
+        scale = max(1.0, float(np.max(np.abs(want_dense))))
+        assert float(np.max(np.abs(got_dense.astype(np.float64) - want_dense))) <= 2e-5 * scale, route
+        if lo:   # elements of the physical output that no logical / view element maps to stay untouched
+            touched = np.zeros(out_floats // 2, bool)
+            for bi in range(batch):
+                for idx in np.ndindex(*reversed(out_shape)):
+                    c = idx[::-1]
+                    touched[lo["offsetElements"] + bi * lo["batchStrideElements"] + sum(c[d] * lo["strides"][d] for d in range(rank))] = True
+            assert np.array_equal(got.reshape(-1, 2)[~touched], sentinel.reshape(-1, 2)[~touched]), route
+        staging = [w for w in ("gather", "embed", "zero-read", "zero-write", "extract", "scatter") if w in route]
+        if fuse:
+            assert not staging and "mapped[" in route, route
+            assert launches == len([a for a in shape if a > 1]) + (1 if (io_view or {}).get("output", {}).get("clearOutside") else 0), route
+        else:
+            assert staging and "mapped[" not in route, route
+
+
 def test_noop_views_resolve_to_nothing():
     _, r = _desc({"type": "c2c", "shape": [8, 4], "direction": "forward", "ioView": {"input": {"shape": [8, 4]}, "output": {"shape": [8, 4], "offset": [0, 0]}},
                   "zeroPad": {"read": {"start": [0, 0], "end": [8, 4]}}})

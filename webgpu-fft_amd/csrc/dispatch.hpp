@@ -48,6 +48,13 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
         }                                                                                \
       }                                                                                  \
       if (a.real_mode != 0) return false;                                                \
+      if constexpr ((IC) == (OC) && (TW) == 0) {                                         \
+        if (a.mapped) {                                                                  \
+          l.launch(fft_lines_mapped_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          return true;                                                                   \
+        }                                                                                \
+      }                                                                                  \
+      if (a.mapped) return false;                                                        \
       l.launch(fft_lines_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
       return true;                                                                       \
     } else return false;                                                                 \
@@ -218,6 +225,8 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.num_tiles = s.i[0]; a.num_lines = s.i[1];
       a.in_S = s.i[2]; a.in_outer_stride = s.i[3]; a.out_S = s.i[4]; a.out_outer_stride = s.i[5];
       a.fs_shift = (int)s.i[6]; a.fs_lo_mask = (unsigned)s.i[7]; a.fs_group = s.i[8] ? s.i[8] : 1; a.real_mode = (int)s.i[9];
+      a.mapped = (int)s.i[10];
+      if (a.mapped) { a.imap = s.imap; a.omap = s.omap; }
       a.scale = s.f[0];
       const LineKernelMeta& m = line_kernel_registry()[(size_t)s.variant];
       return lines_fn(family_of_line_kernel(m), s.variant, a, s.grid);

@@ -27,6 +27,7 @@
 #pragma once
 #include "platform.hpp"
 #include "radix.hpp"
+#include "plan.hpp"
 
 // streamed-once global accesses of the line kernels: 0 = default cache policy, 1 = nontemporal loads + stores
 #ifndef MI355_NT_GLOBAL
@@ -75,6 +76,8 @@ struct LineArgs {
   unsigned fs_lo_mask;
   int real_mode;         // 4: fft_lines_mul_kernel (tw_lo = kernel spectrum, fs_shift != 0: conjugate it);  1: fft_lines_r2c_kernel (real line read as complex pairs, split fused behind the last stage); 2: fft_lines_c2r_kernel
   long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group); COL_RAGGED: tiles per group
+  int mapped;            // fft_lines_mapped_kernel: both sides go through imap / omap (in / out are the buffers' bases)
+  SideMap imap, omap;
 };
 
 template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_, bool SWAP_IN_, bool SWAP_OUT_, int TWID_>
@@ -336,6 +339,111 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
       stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, lo_lds);
+    }
+  }
+}
+
+// ---- mapped sides (src/kernels/ioview.js:56-380, zero_pad.js:21-80, layout_semantics.js:178-232) ---------
+// Line G of a launch -> physical base of its idx = 0 element; false when the line lies outside the side's box on some other dim
+// (`zero`: inside the box but outside the value range on some other dim: a stored line is all zeros).
+MI_DEV bool side_line(const SideMap& m, long long G, long long num_lines, long long& base, bool& zero) {
+  zero = false;
+  if (G >= num_lines) return false;
+  long long rem = G, b = m.offset;
+  bool ok = true;
+  for (int d = 0; d < m.rank; ++d) {
+    if (d == m.ax) continue;
+    const long long q = rem / m.dims[d];
+    const int c = (int)(rem - q * m.dims[d]);
+    rem = q;
+    ok = ok && c >= m.lo[d] && c < m.hi[d];
+    zero = zero || c < m.zlo[d] || c >= m.zhi[d];
+    b += (long long)c * m.stride[d];
+  }
+  base = b + rem * m.batch_stride;
+  return ok;
+}
+
+// The line kernels with both sides mapped: first-stage loads read through imap (zeros outside its box), the stages run as
+// usual with the finished lines KEPT in LDS, and the store pass writes through omap (crop / embed / zero ranges).  One launch
+// does what gather / embed + zero-read + FFT + zero-write + extract / scatter did in up to five.  ROW and column
+// configurations without four-step roots.
+template <class C>
+__global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const LineArgs a) {
+  static_assert(C::IN_COL == C::OUT_COL && C::TWID == TWID_NONE, "ROW or column configuration");
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_lds = lds + C::DATA_ELEMS;
+  const int t = threadIdx.x;
+  if constexpr (C::TW_LDS_ELEMS > 0) {
+    for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
+    __syncthreads();
+  }
+  using I0 = StageInfo<C, 0>;
+  const SideMap& im = a.imap;
+  const SideMap& om = a.omap;
+  for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
+    cf v[C::E];
+    {
+      int line, u; thread_map<C, 0>(t, line, u);
+      long long base = 0; bool zero;
+      const bool ok = side_line(im, tile * C::T + line, a.num_lines, base, zero);
+      const long long sa = im.stride[im.ax];
+      const int lo = im.lo[im.ax], hi = im.hi[im.ax];
+#pragma unroll
+      for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < I0::R; ++q) {
+          const int idx = u + b * C::TPL + q * (C::N / I0::R);
+          cf x = {0.0f, 0.0f};
+          if (ok && idx >= lo && idx < hi) x = a.in[base + (long long)idx * sa];
+          v[b * I0::R + q] = cswap_if<C::SWAP_IN>(x);
+        }
+      }
+    }
+    const long long so = om.stride[om.ax];
+    const int slo = om.lo[om.ax], shi = om.hi[om.ax], zlo = om.zlo[om.ax], zhi = om.zhi[om.ax];
+    if constexpr (C::NSTAGES == 1) {
+      // the whole line sits in one thread's registers (N <= 32): transform and store from there
+      int line, u; thread_map<C, 0>(t, line, u);
+      fft_radix<C::N>(v);
+      long long base = 0; bool zero;
+      if (side_line(om, tile * C::T + line, a.num_lines, base, zero)) {
+#pragma unroll
+        for (int q = 0; q < C::N; ++q) {
+          if (q < slo || q >= shi) continue;
+          cf r = cswap_if<C::SWAP_OUT>(v[q] * a.scale);
+          if (zero || q < zlo || q >= zhi) r = cf{0.0f, 0.0f};
+          a.out[base + (long long)q * so] = r;
+        }
+      }
+    } else {
+      stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
+      __syncthreads();
+      stage_read<C, 1>(v, a, tile, t, lds);
+      __syncthreads();
+      stage_compute_write<C, 1, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+      if constexpr (C::NSTAGES == 3) {
+        __syncthreads();
+        stage_read<C, 2>(v, a, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<C, 2, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+      }
+      __syncthreads();
+      // store pass: a thread stays on one line (its box test and base are computed once), lanes run along the side that is
+      // contiguous in LDS and, for dense targets, in memory
+      int line, u;
+      if constexpr (C::OUT_COL) { line = t % C::T; u = t / C::T; } else { line = t / C::TPL; u = t % C::TPL; }
+      long long base = 0; bool zero;
+      if (side_line(om, tile * C::T + line, a.num_lines, base, zero)) {
+        for (int idx = u; idx < C::N; idx += C::TPL) {
+          if (idx < slo || idx >= shi) continue;
+          cf r = cswap_if<C::SWAP_OUT>(lds[lds_index<C>(line, idx)] * a.scale);
+          if (zero || idx < zlo || idx >= zhi) r = cf{0.0f, 0.0f};
+          a.out[base + (long long)idx * so] = r;
+        }
+      }
+      __syncthreads();   // LDS is re-used by the next tile
     }
   }
 }

@@ -134,6 +134,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_MIXED_LDS_KB")) { const int v = std::atoi(s); if (v >= 8 && v <= 128) o.mixed_lds_kb = v; }
   if (const char* s = std::getenv("MI355FFT_MIXED_THREADS")) { const int v = std::atoi(s); if (v >= 64 && v <= 512 && v % 64 == 0) o.mixed_threads = v; }
   if (const char* s = std::getenv("MI355FFT_ONLY_PASS")) o.only_pass = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_FUSE_VIEWS")) o.fuse_views = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= -1) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
@@ -423,6 +424,45 @@ struct Builder {
     st.grid = lines_grid(*m, tiles, true);
     ir.route += "lines[N=" + std::to_string(N) + ",pitch=" + std::to_string(in_pitch) + "/" + std::to_string(out_pitch) + "] ";
     return true;
+  }
+
+  // ---- mapped sides: strided layouts, ioView and zeroPad carried by the first load / last store -------
+  // Can the pass over an axis of length N with element stride S be a line-kernel launch (ROW for S == 1, column tiles above)?
+  bool axis_mappable(int64_t N, int64_t S, bool inverse) const {
+    if (opt.force_generic || !opt.fuse_views || !is_pow2(N) || N < 2) return false;
+    if (S == 1) return N <= opt.max_line && !(opt.xcd_fused == 2 && N == 4096) && find_line_kernel((int)N, false, false, inverse, inverse, 0) != nullptr;
+    return find_line_kernel((int)N, true, true, inverse, inverse, 0) != nullptr;
+  }
+  static SideMap dense_map(const int64_t* shape, int rank) {
+    SideMap m;
+    m.rank = rank;
+    int64_t st = 1;
+    for (int d = 0; d < rank; ++d) { m.dims[d] = (int)shape[d]; m.stride[d] = st; m.lo[d] = m.zlo[d] = 0; m.hi[d] = m.zhi[d] = (int)shape[d]; st *= shape[d]; }
+    m.batch_stride = st;
+    return m;
+  }
+  // first and last axis emit_nd will transform (-1: none)
+  static void nd_first_last(const int64_t* shape, int rank, uint32_t axes_mask, int& first, int& last) {
+    first = last = -1;
+    for (int a = 0; a < rank; ++a)
+      if (shape[a] > 1 && (axes_mask == 0 || ((axes_mask >> a) & 1u))) { if (first < 0) first = a; last = a; }
+  }
+  // one line-kernel launch over axis `ax` with both sides given as maps (kern_lines.hpp fft_lines_mapped_kernel)
+  int emit_axis_mapped(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, SideMap im, SideMap om, int ax) {
+    const bool col = S > 1;
+    const LineKernelMeta* m = find_line_kernel((int)N, col, col, inverse, inverse, 0);
+    if (!m) return MI355FFT_ERR_UNSUPPORTED;
+    const int64_t lines = S * outer, tiles = (lines + m->T - 1) / m->T;
+    im.ax = om.ax = ax;
+    Step& st = push(ST_LINES);
+    st.variant = m->id;
+    st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m);
+    st.i[0] = tiles; st.i[1] = lines; st.i[2] = S; st.i[3] = S * N; st.i[4] = S; st.i[5] = S * N; st.i[10] = 1;
+    st.f[0] = scale;
+    st.imap = im; st.omap = om;
+    st.grid = lines_grid(*m, tiles);
+    ir.route += std::string(col ? "columns-mapped[N=" : "lines-mapped[N=") + std::to_string(N) + (col ? ",S=" + std::to_string(S) : "") + "] ";
+    return MI355FFT_OK;
   }
 
   int emit_axis(PtrRef src, PtrRef dst, int64_t N, int64_t S, int64_t outer, bool inverse, float scale, std::string& err) {
@@ -750,8 +790,32 @@ struct Builder {
 
   // all axes of a dense [batch][shape] complex array, src -> dst
   // axes_mask: bit a set => axis a is transformed (createFftPlan({axes})); 0 => every axis from first_axis on
+  // imap / omap (optional): the FIRST transformed axis reads `src` through imap, the LAST one writes `fin` through omap; the
+  // passes between work on the dense array at dst.  The caller has checked axis_mappable() for those axes.
   int emit_nd(PtrRef src, PtrRef dst, const int64_t* shape, int rank, int64_t batch, bool inverse, float scale, std::string& err,
-              int first_axis = 0, uint32_t axes_mask = 0) {
+              int first_axis = 0, uint32_t axes_mask = 0, const SideMap* imap = nullptr, const SideMap* omap = nullptr, PtrRef fin = PtrRef()) {
+    if (imap || omap) {
+      int fa, la;
+      nd_first_last(shape, rank, axes_mask, fa, la);
+      const int64_t total = prodv(shape, rank);
+      PtrRef cur = src;
+      int64_t S = 1;
+      for (int a = 0; a < rank; ++a) {
+        const int64_t N = shape[a];
+        if (N > 1 && (axes_mask == 0 || ((axes_mask >> a) & 1u))) {
+          const int64_t outer = batch * (total / (S * N));
+          const bool use_i = a == fa && imap, use_o = a == la && omap;
+          const PtrRef wr = use_o ? fin : dst;
+          int rc;
+          if (use_i || use_o) rc = emit_axis_mapped(cur, wr, N, S, outer, inverse, a == la ? scale : 1.0f, use_i ? *imap : dense_map(shape, rank), use_o ? *omap : dense_map(shape, rank), a);
+          else rc = emit_axis(cur, wr, N, S, outer, inverse, a == la ? scale : 1.0f, err);
+          if (rc) { if (err.empty()) err = "no line kernel for a mapped axis"; return rc; }
+          cur = wr;
+        }
+        S *= N;
+      }
+      return MI355FFT_OK;
+    }
     PtrRef cur = src;
     int64_t S = 1;
     for (int a = 0; a < first_axis; ++a) S *= shape[a];
@@ -967,6 +1031,8 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   PtrRef in(BUF_INPUT, 0), out(d.in_place ? BUF_INPUT : BUF_OUTPUT, 0);
   b.ir.in_bytes = d.input.strided ? strided_extent_elems(d.input, ishape, rank, d.batch, 0) * 8 : (uint64_t)in_n * d.batch * 8;
   b.ir.out_bytes = d.output.strided ? strided_extent_elems(d.output, oshape, rank, d.batch, 0) * 8 : (uint64_t)out_n * d.batch * 8;
+  if (d.axes_mask >> rank) { err = "Invalid axis in axes for rank " + std::to_string(rank); return MI355FFT_ERR_INVALID; }
+  if (vout && d.io_output.clear_outside && d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
 
   // ---- rank-1 lane layouts: unit stride along the line on both sides -> one launch, no staging ----
   if (rank == 1 && !vin && !vout && !d.zero_read.enabled && !d.zero_write.enabled && !d.in_place && (d.input.strided || d.output.strided) &&
@@ -980,9 +1046,54 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       return MI355FFT_OK;
   }
 
-  // ---- input side: dense logical staging when anything but a plain dense read is asked for ----
+  // ---- sides fused into the line kernels: where the first / last transformed axis runs as a line-kernel
+  // launch, that side's strided layout, ioView and zero range become the launch's address map (kern_lines.hpp
+  // fft_lines_mapped_kernel) — no gather / embed / zero / extract / scatter pass and no staging copy of the array
+  int fa = -1, la = -1;
+  Builder::nd_first_last(d.shape, rank, d.axes_mask, fa, la);
+  const auto stride_below = [&](int a) { int64_t S = 1; for (int i = 0; i < a; ++i) S *= d.shape[i]; return S; };
+  const bool need_in = d.input.strided || vin || d.zero_read.enabled;
+  const bool need_out = d.output.strided || vout || d.zero_write.enabled;
+  const bool small = n < ((int64_t)1 << 31);
+  const bool fuse_in = need_in && small && fa >= 0 && b.axis_mappable(d.shape[fa], stride_below(fa), inverse);
+  const bool fuse_out = need_out && small && la >= 0 && b.axis_mappable(d.shape[la], stride_below(la), inverse);
+  SideMap imap, omap;
+  if (fuse_in) {
+    imap = Builder::dense_map(d.shape, rank);
+    int64_t dense = 1;
+    for (int i = 0; i < rank; ++i) {
+      imap.stride[i] = d.input.strided ? d.input.strides[i] : dense;
+      dense *= ishape[i];
+      const int64_t voff = vin ? d.io_input.offset[i] : 0;
+      int64_t lo = std::max<int64_t>(0, voff), hi = vin ? std::min<int64_t>(d.shape[i], voff + d.io_input.shape[i]) : d.shape[i];
+      if (d.zero_read.enabled) { lo = std::max(lo, d.zero_read.start[i]); hi = std::min(hi, d.zero_read.end[i]); }
+      if (hi < lo) hi = lo;
+      imap.lo[i] = (int)lo; imap.hi[i] = (int)hi;
+      imap.offset -= voff * imap.stride[i];
+    }
+    imap.offset += d.input.strided ? d.input.offset_elements : 0;
+    imap.batch_stride = d.input.strided && d.input.batch_stride_elements > 0 ? d.input.batch_stride_elements : in_n;
+  }
+  if (fuse_out) {
+    omap = Builder::dense_map(d.shape, rank);
+    int64_t dense = 1;
+    for (int i = 0; i < rank; ++i) {
+      omap.stride[i] = d.output.strided ? d.output.strides[i] : dense;
+      dense *= oshape[i];
+      const int64_t voff = vout ? d.io_output.offset[i] : 0;
+      int64_t lo = std::max<int64_t>(0, voff), hi = vout ? std::min<int64_t>(d.shape[i], voff + d.io_output.shape[i]) : d.shape[i];
+      if (hi < lo) hi = lo;
+      omap.lo[i] = (int)lo; omap.hi[i] = (int)hi;
+      if (d.zero_write.enabled) { omap.zlo[i] = (int)d.zero_write.start[i]; omap.zhi[i] = (int)d.zero_write.end[i]; }
+      omap.offset -= voff * omap.stride[i];
+    }
+    omap.offset += d.output.strided ? d.output.offset_elements : 0;
+    omap.batch_stride = d.output.strided && d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : out_n;
+  }
+
+  // ---- input side: dense logical staging when anything but a plain dense read is asked for and the first pass cannot map it ----
   PtrRef src = in;
-  const bool stage_in = d.input.strided || vin || (d.zero_read.enabled && !d.in_place);
+  const bool stage_in = !fuse_in && (d.input.strided || vin || (d.zero_read.enabled && !d.in_place));
   if (stage_in) {
     src = b.alloc_work((uint64_t)n * d.batch * 8);
     if (vin) {
@@ -1008,23 +1119,25 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = src; c.i[0] = n * d.batch * 8;
     }
   }
-  if (d.zero_read.enabled) { emit_zero_outside(b, src, d.zero_read, d.shape, rank, d.batch); b.ir.route += "zero-read "; }
+  if (d.zero_read.enabled && !fuse_in) { emit_zero_outside(b, src, d.zero_read, d.shape, rank, d.batch); b.ir.route += "zero-read "; }
 
   // ---- transform ----
-  const bool stage_out = d.output.strided || vout;
+  // dst: the dense array the passes work on.  A staged or mapped output side needs one that is not the caller's output: the
+  // input staging if there is one, else workspace — except when a single pass maps both sides (in -> out directly).
+  const bool stage_out = !fuse_out && (d.output.strided || vout);
   PtrRef dst = out;
-  if (stage_out) dst = stage_in ? src : b.alloc_work((uint64_t)n * d.batch * 8);
-  if (d.axes_mask >> rank) { err = "Invalid axis in axes for rank " + std::to_string(rank); return MI355FFT_ERR_INVALID; }
-  rc = b.emit_nd(src, dst, d.shape, rank, d.batch, inverse, scale, err, 0, d.axes_mask);
+  if (stage_out || (fuse_out && (d.output.strided || vout) && !(fuse_in && fa == la))) dst = stage_in ? src : b.alloc_work((uint64_t)n * d.batch * 8);
+  if (fuse_out && vout && d.io_output.clear_outside) {   // view elements outside the logical domain: zeroed before the store pass
+    Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * 2; z.grid = b.generic_grid(z.i[0]);
+  }
+  rc = b.emit_nd(src, dst, d.shape, rank, d.batch, inverse, scale, err, 0, d.axes_mask, fuse_in ? &imap : nullptr, fuse_out ? &omap : nullptr, out);
   if (rc) return rc;
+  if (fuse_out) return MI355FFT_OK;
   if (d.zero_write.enabled) { emit_zero_outside(b, dst, d.zero_write, d.shape, rank, d.batch); b.ir.route += "zero-write "; }
 
   // ---- output side ----
   if (vout) {
-    if (d.io_output.clear_outside) {
-      if (d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
-      Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * 2; z.grid = b.generic_grid(z.i[0]);
-    }
+    if (d.io_output.clear_outside) { Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * 2; z.grid = b.generic_grid(z.i[0]); }
     int64_t ext[8], ls[8], vs[8];
     if (view_region(d.io_output, d.shape, rank, ext, ls, vs)) {
       mi355fft_side_layout lay = d.output;

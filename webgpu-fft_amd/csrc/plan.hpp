@@ -80,6 +80,19 @@ struct PtrRef {
   bool same(const PtrRef& o) const { return buf == o.buf && off == o.off; }
 };
 
+// A side of a line-kernel launch as a map from logical coordinates to physical storage (layout strides,
+// ioView, zeroPad fused into the first load / last store instead of separate gather / embed / zero / extract / scatter passes).
+// Line G of the launch (all dims except `ax` in axis-0-fastest order, then the batch) and position idx along `ax`:
+//   reads : inside [lo, hi) on every dim -> phys[offset + sum i_d * stride_d + b * batch_stride], else 0
+//   writes: inside [lo, hi) on every dim -> stored, with the value replaced by 0 outside [zlo, zhi); else not stored
+struct SideMap {
+  int rank = 0, ax = 0;
+  int dims[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+  int lo[8] = {0}, hi[8] = {0}, zlo[8] = {0}, zhi[8] = {0};
+  long long stride[8] = {0};
+  long long offset = 0, batch_stride = 0;
+};
+
 enum StepKind : int {
   ST_LINES, ST_STAGE, ST_R2C_POST, ST_C2R_PRE, ST_REAL_TO_COMPLEX, ST_COMPLEX_TO_REAL, ST_PACK_HALF, ST_UNPACK_HERM,
   ST_POINTWISE, ST_GATHER, ST_SCATTER, ST_ZERO, ST_COPY, ST_SCALE, ST_FFTCONV_FUSED, ST_CHIRP_PRE, ST_CHIRP_POST, ST_ZERO_OUTSIDE, ST_XCD_FUSED, ST_LINES_MIXED, ST_TRIG_PRE, ST_TRIG_POST, ST_XCD_RES
@@ -93,6 +106,7 @@ struct Step {
   int64_t i[20] = {0};     // kind-specific integers
   float f[2] = {1.0f, 1.0f}; // kind-specific floats
   int64_t shape[8] = {0}, sa[8] = {0}, sb[8] = {0};  // ST_GATHER / ST_SCATTER
+  SideMap imap, omap;        // ST_LINES with i[10] != 0: mapped sides (kern_lines.hpp fft_lines_mapped_kernel)
   unsigned grid = 1;
 };
 
@@ -108,6 +122,7 @@ struct PlanIR {
 struct PlannerOptions {
   uint64_t chunk_bytes = 1ull << 30;   // two-pass: bytes of inter-pass intermediate per launch pair (measured: larger is faster)
   int compute_units = 256;
+  int fuse_views = 1;                  // c2c: strided layouts / ioView / zeroPad ride the first load and last store of the line kernels where the axis route allows (0: staging passes)
   int lines_tiles_per_wg = 0;          // line kernels: 0 = resident grid (CUs x workgroups per CU) walking the tiles; k > 0 = one workgroup per k tiles
   int force_generic = 0;               // tests: route everything through the global-memory stage kernels
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
