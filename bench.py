@@ -257,7 +257,7 @@ def main():
     if args.workload not in WORKLOADS:   # probes (never the headline line): c2c_2pL_bB, r2c_n1000_bB, c2c_s1024x1024_bB ...
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r|fftconv|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
-        nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)+\d+)_b(\d+)(_view)?", args.workload)      # N-D: axis 0 first; _view: padded read + cropped write
+        nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)*\d+)_b(\d+)(_view)?", args.workload)      # N-D: axis 0 first; _view: padded read + cropped write
         if nd:
             ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
             tot = 1

@@ -361,10 +361,13 @@ def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle):
     assert np.count_nonzero(got == 77.0) == (5000 - n) * batch
 
 
-def test_c2c_ioview_and_zeropad(fft, dev, oracle):
-    """pad-in-read + embed-in-write (clearOutside) + range zeroing, checked against the emu-tier numpy restatement"""
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_c2c_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
+    """pad-in-read + embed-in-write (clearOutside) + range zeroing, checked against the emu-tier numpy restatement.  fuse=1: both
+    sides ride the first load / last store of the line kernels (no separate passes); fuse=0: the staging route"""
     from test_emu_ioview import reference
     from mi355fft.layout import resolve_plan_options
+    monkeypatch.setenv("MI355FFT_FUSE_VIEWS", str(fuse))
     shape, batch = [64, 8], 3
     opts = {"type": "c2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "unitary",
             "ioView": {"input": {"shape": [40, 8], "placement": "center"}, "output": {"shape": [80, 10], "placement": "center", "clearOutside": True}},
@@ -374,7 +377,10 @@ def test_c2c_ioview_and_zeropad(fft, dev, oracle):
     out_floats = 2 * 80 * 10 * batch
     sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
     got, (route, _) = run_plan(fft, dev, opts, x, out_floats, out_init=sentinel)
-    assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
+    if fuse:
+        assert route.split() == ["lines-mapped[N=64]", "columns-mapped[N=8,S=64]"], route
+    else:
+        assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
     want = reference(oracle, x, shape, batch, "forward", "unitary", r["io_view"]["input"], r["io_view"]["output"], r["zero_pad"]["read"],
                      r["zero_pad"]["write"], sentinel)
     assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * max(1.0, float(np.max(np.abs(want))))

@@ -213,7 +213,9 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
 
 // KEEP_IN_LDS: the last stage leaves the finished lines in LDS (same layout as the exchanges) instead of storing them to
 // global memory — for kernels that post-process a whole line before it leaves the workgroup (kern_xcd_real.hpp)
-template <class C, int S, bool NT = false, bool KEEP_IN_LDS = false>
+// MUL: the finished outputs are multiplied by the spectrum a.tw_lo[k] (conjugated when a.fs_shift != 0) on their way out — the
+// pointwise product of fftconv folded into the last stage's register store (fft_lines_mul_kernel)
+template <class C, int S, bool NT = false, bool KEEP_IN_LDS = false, bool MUL = false>
 MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile, int t, cf* lds, const cf* tw_lds, const cf* lo_lds) {
   using I = StageInfo<C, S>;
   constexpr bool TO_GLOBAL = I::LAST && !KEEP_IN_LDS;
@@ -262,6 +264,11 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
           const cf lo = lo_lds[m & a.fs_lo_mask];
           const cf hi = a.tw_hi[m >> a.fs_shift];
           r = cmul(r, cmul(hi, lo));
+        }
+        if constexpr (MUL) {
+          cf h = a.tw_lo[oidx];
+          if (a.fs_shift) h.y = -h.y;
+          r = cmul(r, h);
         }
         if (a.scale != 1.0f) r = r * a.scale;
         // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
@@ -503,9 +510,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
   }
 }
 
-// fftconv, first half (src/kernels/fft_conv.js:3-66 pointwise product): forward FFT of complex lines with the
-// finished lines KEPT in LDS, multiplied there by the kernel spectrum a.tw_lo[k] (its conjugate when a.fs_shift != 0: correlation)
-// and stored — the separate pointwise pass (8 B read + 8 B written per point) disappears.  One spectrum for every line.
+// fftconv, first half (src/kernels/fft_conv.js:3-66 pointwise product): forward FFT of complex lines whose
+// outputs are multiplied by the kernel spectrum a.tw_lo[k] (its conjugate when a.fs_shift != 0: correlation) as they are stored —
+// the separate pointwise pass (8 B read + 8 B written per point) disappears.  One spectrum for every line.
 template <class C>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
@@ -517,31 +524,24 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
     for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
     __syncthreads();
   }
-  const float ksign = a.fs_shift ? -1.0f : 1.0f;
+  // the product rides the last stage's register store (MUL): the line never goes back to LDS.  (Round 1 kept the finished lines in
+  // LDS and multiplied in a second sweep: 271 us against 198 us for the plain transform over the same bytes.)
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
     stage_read<C, 0>(v, a, tile, t, lds);
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
-    __syncthreads();
+    lines_sync<C>();
     stage_read<C, 1>(v, a, tile, t, lds);
-    __syncthreads();
-    stage_compute_write<C, 1, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
-    if constexpr (C::NSTAGES == 3) {
-      __syncthreads();
+    lines_sync<C>();
+    if constexpr (C::NSTAGES == 2) {
+      stage_compute_write<C, 1, false, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+    } else {
+      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, nullptr);
+      lines_sync<C>();
       stage_read<C, 2>(v, a, tile, t, lds);
-      __syncthreads();
-      stage_compute_write<C, 2, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+      lines_sync<C>();
+      stage_compute_write<C, 2, false, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
     }
-    __syncthreads();
-    const long long G0 = tile * C::T;
-    const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
-    for (int p = t; p < live * C::N; p += C::THREADS) {
-      const int line = p / C::N, k = p - line * C::N;
-      cf h = a.tw_lo[k];
-      h.y *= ksign;
-      a.out[(G0 + line) * a.out_outer_stride + k] = cmul(lds[lds_index<C>(line, k)], h) * a.scale;
-    }
-    __syncthreads();   // LDS is re-used by the next tile
   }
 }
 

@@ -32,14 +32,26 @@ struct TrigArgs {
   long long stride;   // kinds >= 8: element stride of the axis (1: the dense kernels; > 1: the tiled ones)
 };
 
-MI_DEV cf trig_phase(double turns_half) {   // e^{i pi t}
-  double s, c;
-#ifdef MI355_HOST_EMU
-  s = std::sin(3.14159265358979323846 * turns_half); c = std::cos(3.14159265358979323846 * turns_half);
-#else
-  sincospi(turns_half, &s, &c);
+// e^{i pi t}, |t| <= 2.  The argument arrives in f64 (m / 2N is formed exactly enough there) and is reduced to f32 for the
+// evaluation: an f64 sincospi per element (~100 f64 operations) held the phase passes at 3.5 TB/s
+// (profiles/r01_rocprof_widened_rows.log); the f32 evaluation of pi*t is good to a few 1e-7 absolute, two orders below the
+// 1e-5 bar.  MI355_TRIG_F64_PHASE=1 restores the f64 form.
+#ifndef MI355_TRIG_F64_PHASE
+#define MI355_TRIG_F64_PHASE 0
 #endif
-  cf r; r.x = (float)c; r.y = (float)s;
+MI_DEV cf trig_phase(double turns_half) {
+  cf r;
+#ifdef MI355_HOST_EMU
+  r.x = (float)std::cos(3.14159265358979323846 * turns_half); r.y = (float)std::sin(3.14159265358979323846 * turns_half);
+#elif MI355_TRIG_F64_PHASE
+  double s, c;
+  sincospi(turns_half, &s, &c);
+  r.x = (float)c; r.y = (float)s;
+#else
+  float s, c;
+  sincospif((float)turns_half, &s, &c);
+  r.x = c; r.y = s;
+#endif
   return r;
 }
 

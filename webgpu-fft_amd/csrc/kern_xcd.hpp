@@ -106,10 +106,24 @@ MI_DEV void fourstep_apply_chain(cf (&v)[C::E], const XcdFusedArgs& a, unsigned 
 // split barrier over the workgroups of one XCD.  arrive: this workgroup's stores are complete in the shared L2
 // (s_waitcnt vmcnt(0) in every wave, then the workgroup barrier), one lane bumps the group counter.  wait: one lane polls
 // (relaxed agent-scope loads, bounded), then an agent-scope acquire drops this CU's L1 before anyone reads.
+// MI355_XCD_RELEASE=1 (A/B builds only): the form the hardware guide lists — lane 0 issues an agent-scope release (buffer_wbl2:
+// write back this XCD's dirty L2 lines) before the add.  The shipped form omits it: producer and consumers of a group sit behind
+// the SAME L2 by construction (groups are formed from the XCC_ID register), so the stores are visible to them once they have left
+// the CU (vmcnt(0)), and writing W back to memory first is exactly the fabric traffic the kernel is trying not to wait for.
+// Measured: profiles/r02_xcd_handoff_release_ab.log.
+#ifndef MI355_XCD_RELEASE
+#define MI355_XCD_RELEASE 0
+#endif
 MI_DEV void xcd_arrive(unsigned* counter) {
   MI_WAIT_VMEM();
   __syncthreads();
-  if (threadIdx.x == 0) MI_ATOMIC_ADD_U32(counter, 1u);
+  if (threadIdx.x == 0) {
+#if MI355_XCD_RELEASE && !defined(MI355_HOST_EMU)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    MI_WAIT_VMEM();
+#endif
+    MI_ATOMIC_ADD_U32(counter, 1u);
+  }
 }
 // solo mode: producer and consumer are the same workgroup — its stores are complete (vmcnt(0) + workgroup barrier) and its
 // CU's L1 is invalidated (the slot is re-used for every transform, so stale lines of the previous one may sit there)
