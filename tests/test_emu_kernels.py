@@ -82,6 +82,7 @@ def test_c2c_two_pass_2p22(oracle):
 def test_c2c_generic_mixed_radix(oracle, monkeypatch, n, mixed):
     """mixed-radix lengths on the one-launch LDS line kernel (kern_mixed.hpp) and on the global-memory stage route"""
     monkeypatch.setenv("MI355_EMU_MIXED_LINES", str(2 * mixed))   # 2: also where the planner would keep the stage route
+    monkeypatch.setenv("MI355_EMU_MIXED_CT", "0")                 # the compile-time-plan instances have their own test below
     batch = 5 if n < 200 else 2
     x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
@@ -94,7 +95,24 @@ def test_c2c_generic_mixed_radix(oracle, monkeypatch, n, mixed):
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 2e-6 if n < 1000 else 1e-5)
 
 
-@pytest.mark.parametrize("shape,expect", [([96, 105], 2), ([24, 25, 27], 3), ([6, 10, 4], 2), ([1000, 3], 1)])
+MIXED_CT = [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 120, 240, 480, 720, 1440]
+
+
+@pytest.mark.parametrize("n", MIXED_CT)
+def test_c2c_mixed_radix_compile_time_plans(oracle, n):
+    """every instance of kern_mixed_ct.hpp (MI355_MIXEDCT_LIST in plan.hpp): lengths 3*2^k, 5*2^k, 1000 and the reference's
+    mixed-radix test sizes with radices, tile shape and thread count as template constants; batches that leave a ragged last tile"""
+    from mi355fft import _abi as abi
+    batch = {True: 37, False: 3}[n < 400]
+    x = oracle.random_complex_batch(n, batch, 0xC700 + n).reshape(-1)
+    for direction, norm in (("forward", "unitary"), ("inverse", "backward")):
+        desc = abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith("mixed-ct[N=%d," % n) and launches == 1, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 2e-6 if n < 1000 else 1e-5)
+
+
+@pytest.mark.parametrize("shape,expect", [([96, 105], 1), ([24, 25, 27], 3), ([6, 10, 4], 2), ([1000, 3], 0)])
 def test_c2c_nd_mixed_radix_lines(oracle, shape, expect):
     """N-D shapes of the reference's suites (complete.suite.js:876-913): every axis, contiguous or strided, in one launch"""
     batch = 2

@@ -13,6 +13,7 @@
 #include "kern_generic.hpp"
 #include "kern_lines.hpp"
 #include "kern_mixed.hpp"
+#include "kern_mixed_ct.hpp"
 #include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
 #include "kern_xcd_res.hpp"
@@ -189,6 +190,24 @@ template <class L> bool launch_xcd_res(int variant, const XcdFusedArgs& a, unsig
 }
 #endif
 
+// mixed-radix kernels with compile-time plans: own translation unit (mixed_ct_kernels.hip) in the product build
+template <class L> bool launch_mixedct(int id, const MixedArgs& a, unsigned grid, L& l);
+#if defined(MI355_MIXEDCT_DEFINE_INSTANCES) || defined(MI355_HOST_EMU)
+template <class L> bool launch_mixedct(int id, const MixedArgs& a, unsigned grid, L& l) {
+  int cur = 0;
+#define X(N, T, TH, ...)                                                                                   \
+  if (id == cur++) {                                                                                       \
+    using M = MixedCt<N, T, TH, __VA_ARGS__>;                                                              \
+    l.launch(fft_lines_mixedct_kernel<M>, grid, (unsigned)M::THREADS, (unsigned)M::LDS_BYTES, a);        \
+    return true;                                                                                           \
+  }
+  MI355_MIXEDCT_LIST(X)
+#undef X
+  (void)cur;
+  return false;
+}
+#endif
+
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
   switch (radix) {
 #define MI_STAGE_CASE(R) case R: l.launch(stockham_stage_kernel<R>, grid, 256u, 0u, a); return true;
@@ -249,6 +268,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.lines = s.i[0]; a.N = (int)s.i[1]; a.S = s.i[2]; a.T = (int)s.i[3]; a.nst = (int)s.i[4];
       a.swap_in = a.swap_out = (int)s.i[5];
       a.scale = s.f[0];
+      if (s.variant > 0) return launch_mixedct(s.variant - 1, a, s.grid, l);   // compile-time plan: nothing else to pass
       {
         const auto rcp = [](unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; };
         unsigned nsp = 1;

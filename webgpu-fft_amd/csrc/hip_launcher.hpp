@@ -77,6 +77,7 @@ extern template bool launch_lines_family<FAM_ROW_BIG, HipLauncher>(int, const Li
 extern template bool launch_lines_family<FAM_PASS_A, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 extern template bool launch_lines_family<FAM_PASS_B, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 
+extern template bool launch_mixedct<HipLauncher>(int, const MixedArgs&, unsigned, HipLauncher&);
 extern template bool launch_xcd_res<HipLauncher>(int, const XcdFusedArgs&, unsigned, HipLauncher&);
 
 }  // namespace mi355

@@ -115,6 +115,10 @@ struct LineCfg {
   // software pipelining of the resident workgroup's tile loop: the first-stage loads of the NEXT tile are issued before the
   // current tile is computed and stored, so the memory system always has this workgroup's reads in flight (E more complex
   // registers per thread).  ROW kernels of 64..2048 points: their register budget allows it at the occupancy the LDS permits.
+  // plain ROW transforms of 256 points and more stream every byte once: nontemporal loads / stores measured +4...+6 % on the
+  // one-shot and on the resident grids (N = 64: -10 %; profiles/r02_lines_nt_ab.log).  The XCD kernels pick their own policy per
+  // call site (their intermediate must stay cached), the fused r2c / c2r / product variants keep the default.
+  static constexpr bool STREAM_NT = !IN_COL && !OUT_COL && TWID == TWID_NONE && N >= 256;
   static constexpr bool PREFETCH = MI355_LINES_PREFETCH && !IN_COL && !OUT_COL && TWID == TWID_NONE && NSTAGES == 2 && N >= 64 && N <= 2048;
   static_assert(THREADS <= 1024, "workgroup too large");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
@@ -265,11 +269,7 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
           const cf hi = a.tw_hi[m >> a.fs_shift];
           r = cmul(r, cmul(hi, lo));
         }
-        if constexpr (MUL) {
-          cf h = a.tw_lo[oidx];
-          if (a.fs_shift) h.y = -h.y;
-          r = cmul(r, h);
-        }
+        if constexpr (MUL) r = cmul(r, lo_lds[b * I::R + q]);   // this thread's slice of the spectrum, held in registers by the caller
         if (a.scale != 1.0f) r = r * a.scale;
         // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
         cf* pq = po + (unsigned)(b * C::TPL + q * I::NSP) * es;
@@ -297,15 +297,15 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
     __syncthreads();
     cf v[C::E], vn[C::E];
     long long tile = blockIdx.x;
-    if (tile < a.num_tiles) stage_read<C, 0>(v, a, tile, t, lds);
+    if (tile < a.num_tiles) stage_read<C, 0, C::STREAM_NT>(v, a, tile, t, lds);
     for (; tile < a.num_tiles; tile += gridDim.x) {
       const long long next = tile + gridDim.x;
-      if (next < a.num_tiles) stage_read<C, 0>(vn, a, next, t, lds);      // in flight while this tile is computed and stored
+      if (next < a.num_tiles) stage_read<C, 0, C::STREAM_NT>(vn, a, next, t, lds);      // in flight while this tile is computed and stored
       stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, lo_lds);
       lines_sync<C>();
       stage_read<C, 1>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, lo_lds);
+      stage_compute_write<C, 1, C::STREAM_NT>(v, a, tile, t, lds, tw_lds, lo_lds);
 #pragma unroll
       for (int e = 0; e < C::E; ++e) v[e] = vn[e];
     }
@@ -326,26 +326,27 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
   const bool fs_hoist = C::TWID == TWID_FOURSTEP_IN && ((long long)gridDim.x * C::T) % a.fs_group == 0;
   if constexpr (C::TWID == TWID_FOURSTEP_IN) { if (fs_hoist) fourstep_in_roots<C>(fsw, a, blockIdx.x, t); }
 
+  constexpr bool SNT = C::STREAM_NT;
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
-    stage_read<C, 0>(v, a, tile, t, lds);
+    stage_read<C, 0, SNT>(v, a, tile, t, lds);
     if constexpr (C::TWID == TWID_FOURSTEP_IN) {
       if (!fs_hoist) fourstep_in_roots<C>(fsw, a, tile, t);
 #pragma unroll
       for (int e = 0; e < C::E; ++e) v[e] = cmul(v[e], fsw[e]);
     }
-    stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, lo_lds);
+    stage_compute_write<C, 0, SNT>(v, a, tile, t, lds, tw_lds, lo_lds);     // (NT only matters where a stage stores to memory)
     if constexpr (C::NSTAGES >= 2) {
       lines_sync<C>();
       stage_read<C, 1>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, lo_lds);
+      stage_compute_write<C, 1, SNT>(v, a, tile, t, lds, tw_lds, lo_lds);
     }
     if constexpr (C::NSTAGES == 3) {
       lines_sync<C>();
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, lo_lds);
+      stage_compute_write<C, 2, SNT>(v, a, tile, t, lds, tw_lds, lo_lds);
     }
   }
 }
@@ -524,8 +525,24 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
     for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
     __syncthreads();
   }
-  // the product rides the last stage's register store (MUL): the line never goes back to LDS.  (Round 1 kept the finished lines in
-  // LDS and multiplied in a second sweep: 271 us against 198 us for the plain transform over the same bytes.)
+  // the product rides the last stage's register store (MUL): the line never goes back to LDS, and the spectrum values a thread
+  // needs are the same for every tile (its output indices do not depend on the tile), so they are loaded ONCE per workgroup into
+  // registers.  (Round 1 multiplied in a second sweep over the line kept in LDS; re-reading the spectrum per tile in the store
+  // path costs the same 271 us against 190 us for the plain transform over the same bytes.)
+  cf hk[C::E];
+  {
+    using IL = StageInfo<C, C::NSTAGES - 1>;
+    int line, u; thread_map<C, C::NSTAGES - 1>(t, line, u);
+#pragma unroll
+    for (int b = 0; b < IL::NB; ++b) {
+#pragma unroll
+      for (int q = 0; q < IL::R; ++q) {
+        cf h = a.tw_lo[u + b * C::TPL + q * IL::NSP];      // last stage: output index = j + q * Ns_prev, j = u + b * TPL
+        if (a.fs_shift) h.y = -h.y;
+        hk[b * IL::R + q] = h;
+      }
+    }
+  }
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
     stage_read<C, 0>(v, a, tile, t, lds);
@@ -534,13 +551,13 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
     stage_read<C, 1>(v, a, tile, t, lds);
     lines_sync<C>();
     if constexpr (C::NSTAGES == 2) {
-      stage_compute_write<C, 1, false, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 1, false, false, true>(v, a, tile, t, lds, tw_lds, hk);
     } else {
       stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, nullptr);
       lines_sync<C>();
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 2, false, false, true>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 2, false, false, true>(v, a, tile, t, lds, tw_lds, hk);
     }
   }
 }

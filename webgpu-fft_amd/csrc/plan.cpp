@@ -125,6 +125,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_CHUNK_BYTES")) { const int64_t v = std::atoll(s); if (v > 0) o.chunk_bytes = (uint64_t)v; }
   if (const char* s = std::getenv("MI355FFT_FORCE_GENERIC")) o.force_generic = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_MIXED_LINES")) o.mixed_lines = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_MIXED_CT")) o.mixed_ct = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_C2R")) o.lines_c2r = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_TRIG_REAL")) o.trig_real = std::atoi(s);
@@ -147,6 +148,19 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
   return o;
+}
+
+const std::vector<MixedCtMeta>& mixedct_registry() {
+  static const std::vector<MixedCtMeta> reg = [] {
+    std::vector<MixedCtMeta> r;
+    int id = 0;
+#define X(N_, T_, TH_, ...) { MixedCtMeta m; m.id = id++; m.N = N_; m.T = T_; m.threads = TH_; m.radices = std::vector<int>{__VA_ARGS__}; \
+    int tw = 0, nsp = 1; for (int R : m.radices) { tw += R * nsp; nsp *= R; } m.lds_bytes = (2 * T_ * (N_ + (N_ >> 5) + 1) + tw) * 8; r.push_back(m); }
+    MI355_MIXEDCT_LIST(X)
+#undef X
+    return r;
+  }();
+  return reg;
 }
 
 // max_radix < 32: the one-launch mixed-radix kernel keeps a line in LDS, where a stage is cheap but its parallelism is
@@ -638,6 +652,32 @@ struct Builder {
     // (short lines that the stage route finishes in three passes with a radix-16/32 first stage measured faster there: 640, 768)
     // (strided axes need T >= 8 adjacent lines per workgroup for coalesced accesses: N <= 512; longer ones keep the stage route —
     // measured 27 GPoints/s for the 4096-point axis of a 4096x4096 array with T = 1)
+    // dense lines of a length with a compile-time-plan instance (kern_mixed_ct.hpp)
+    if (opt.mixed_lines && opt.mixed_ct && !opt.force_generic && S == 1) {
+      const MixedCtMeta* cm = nullptr;
+      for (const auto& m : mixedct_registry()) if (m.N == N) cm = &m;
+      if (cm) {
+        std::vector<float2h> t;
+        Step& st = push(ST_LINES_MIXED);
+        int64_t nsp = 1;
+        for (int R : cm->radices) {
+          const size_t off = t.size();
+          t.resize(off + (size_t)(R * nsp));
+          for (int q = 0; q < R; ++q) for (int64_t k = 0; k < nsp; ++k) t[off + (size_t)(q * nsp + k)] = root_of_unity(q * k, nsp * R);
+          nsp *= R;
+        }
+        st.variant = cm->id + 1;
+        st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
+        st.i[0] = lines; st.i[1] = N; st.i[2] = 1; st.i[3] = cm->T; st.i[4] = (int64_t)cm->radices.size();
+        st.i[5] = inverse ? 1 : 0; st.i[7] = cm->threads;
+        st.f[0] = scale;
+        const int64_t tiles = (lines + cm->T - 1) / cm->T;
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / (cm->lds_bytes + 1024), 2048 / cm->threads), 8));
+        st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)opt.compute_units * per_cu));
+        ir.route += "mixed-ct[N=" + std::to_string(N) + ",T=" + std::to_string(cm->T) + ",n=" + std::to_string(cm->radices.size()) + "] ";
+        return MI355FFT_OK;
+      }
+    }
     const bool stages_win = ((S == 1 && N < 1024 && radices.size() == 3 && radices[0] >= 16) || (S > 1 && N > 512)) && opt.mixed_lines != 2;
     if (opt.mixed_lines && !opt.force_generic && !stages_win && lds_radices.size() >= 2 && lds_radices.size() <= 12 && N <= 4096) {
       const std::vector<int>& radices = lds_radices;

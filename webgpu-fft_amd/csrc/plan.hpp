@@ -37,6 +37,18 @@ const LineKernelMeta* find_line_kernel(int N, bool in_col, bool out_col, bool sw
   X(64, 8, 8, 4) X(64, 8, 8, 16) X(128, 16, 8, 4) X(128, 16, 8, 16) X(256, 16, 16, 4) X(256, 16, 16, 16) \
   X(512, 32, 16, 4) X(512, 32, 16, 16) X(1024, 32, 32, 4) X(1024, 32, 32, 16)
 struct ConvKernelMeta { int id, N, R0, R1, TL; };
+// mixed-radix line kernels with compile-time plans (kern_mixed_ct.hpp): id = position in the list
+// instances: X(N, lines per workgroup, threads, radices...).  Tile shapes keep every stage's butterfly count (T * N / R) at or
+// above the thread count and two workgroups per CU inside the LDS.
+#define MI355_MIXEDCT_LIST(X)                                                                                                   \
+  X(96, 32, 256, 8, 4, 3) X(192, 16, 256, 8, 8, 3) X(384, 8, 256, 8, 8, 2, 3) X(768, 4, 256, 8, 8, 4, 3) X(1536, 2, 256, 8, 8, 8, 3)       \
+  X(3072, 1, 256, 8, 8, 8, 2, 3) X(160, 16, 256, 8, 4, 5) X(320, 8, 256, 8, 8, 5) X(640, 4, 256, 8, 8, 2, 5) X(1280, 2, 256, 8, 8, 4, 5)  \
+  X(2560, 1, 256, 8, 8, 8, 5) X(1000, 4, 256, 8, 5, 5, 5) X(2000, 2, 256, 8, 2, 5, 5, 5) X(3000, 1, 256, 8, 5, 5, 5, 3)                   \
+  X(105, 32, 256, 7, 5, 3) X(1001, 4, 256, 13, 11, 7) X(360, 8, 256, 8, 5, 3, 3) X(1920, 2, 256, 8, 8, 2, 5, 3) X(2187, 1, 256, 3, 3, 3, 3, 3, 3, 3) \
+  X(120, 32, 256, 8, 5, 3) X(240, 16, 256, 8, 2, 5, 3) X(480, 8, 256, 8, 4, 5, 3) X(720, 4, 256, 8, 2, 5, 3, 3) X(1440, 2, 256, 8, 4, 5, 3, 3)
+
+struct MixedCtMeta { int id, N, T, threads, lds_bytes; std::vector<int> radices; };
+const std::vector<MixedCtMeta>& mixedct_registry();
 
 // XCD-fused four-step kernels (kern_xcd.hpp): X(N1, R0a, R1a, R2a, Ta, N2, R0b, R1b, R2b, Tb); the tile widths are chosen so
 // that both passes use the same workgroup size; each is built forward and inverse.  (64 x 64 exists for the CPU
@@ -136,6 +148,7 @@ struct PlannerOptions {
   int solo_cap_mb = 1024;              // solo mode: all workgroups' workspace slots together (MiB); occupancy matters more than the footprint
   int solo_max_kb = 1024;              // transforms up to this size run in solo mode
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
+  int mixed_ct = 1;                    // mixed-radix lengths with a compile-time-plan instance (kern_mixed_ct.hpp) use it (dense lines)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
   int64_t conv_fused_max_points = (int64_t)1 << 20;   // fftconv-fused (one launch, latency route) up to this many points B*N*K; above: forward-mul + inverse line launches
