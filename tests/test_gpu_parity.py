@@ -234,6 +234,7 @@ def test_c2c_large_golden_samples(fft, dev, oracle, manifest):
 def test_c2c_mixed_radix(fft, dev, oracle, monkeypatch, n, mixed):
     """mixed-radix lengths: the one-launch LDS line kernel (N <= 4096, >= 2 stages) and the global-memory stage route"""
     monkeypatch.setenv("MI355FFT_MIXED_LINES", str(2 * mixed))   # 2: also where the planner would keep the stage route
+    monkeypatch.setenv("MI355FFT_MIXED_CT", "0")                 # (the compile-time-plan instances: test_c2c_mixed_radix_compile_time_plans)
     batch = 300 if n < 200 else (37 if n < 2000 else 5)   # several tiles per workgroup, ragged last tile; the O(N^2) oracle bounds the rest
     x = oracle.random_complex_batch(n, batch, 0xC000 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
@@ -242,6 +243,18 @@ def test_c2c_mixed_radix(fft, dev, oracle, monkeypatch, n, mixed):
             assert route.startswith("mixed-lines[") and launches == 1, route
         else:
             assert route.startswith("stages["), route
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 3e-3, 3e-3)
+
+
+@pytest.mark.parametrize("n", [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 120, 240, 480, 720, 1440])
+def test_c2c_mixed_radix_compile_time_plans(fft, dev, oracle, n):
+    """every instance of kern_mixed_ct.hpp: radices, tile shape and threads as template constants (232 vs 85 GPoints/s at N=1000);
+    batches with several tiles per workgroup and a ragged last tile, against the oracle's O(N^2) DFT"""
+    batch = 301 if n < 400 else (37 if n < 2000 else 7)
+    x = oracle.random_complex_batch(n, batch, 0xC700 + n).reshape(-1)
+    for direction, norm in (("forward", "unitary"), ("inverse", "backward")):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert route.startswith("mixed-ct[N=%d," % n) and launches == 1, route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 3e-3, 3e-3)
 
 

@@ -217,10 +217,11 @@ struct Builder {
     ir.table.insert(ir.table.end(), t.begin(), t.end());
     return r;
   }
+  // element-wise kernels (grid-stride loops of 256 threads): one element per thread.  Round 1 capped the grid at 16 workgroups per
+  // CU; one-shot grids stream 15-20 % faster on this chip (profiles/r02_copy_ceiling.log), so the cap is only an overflow guard.
   unsigned generic_grid(int64_t total) const {
     const int64_t blocks = (total + 255) / 256;
-    const int64_t cap = (int64_t)opt.compute_units * 16;
-    return (unsigned)std::max<int64_t>(1, std::min(blocks, cap));
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)1 << 30));
   }
   // streaming kernels whose work items are independent chunks: one short-lived workgroup per item.  One-shot grids stream at
   // 6.2-6.5 TB/s on this chip where resident grid-stride loops reach 5.3-5.5 (profiles/r02_copy_ceiling.log)
@@ -1325,8 +1326,8 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       pre.p[0] = cur; pre.p[1] = V; pre.p[2] = quarter ? dst : v;
       pre.i[0] = lines; pre.i[1] = N; pre.i[2] = P; pre.i[3] = M; pre.i[4] = rkind; pre.i[5] = S;
       // S > 1 (axes >= 1): 32 x 32 tiles through LDS, one workgroup per tile
-      const auto tiled_grid = [&](int64_t per) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((lines / S) * ((S + 31) / 32) * ((per + 31) / 32), (int64_t)b.opt.compute_units * 16)); };
-      pre.grid = S > 1 ? tiled_grid(tinv || quarter ? P : M) : b.generic_grid(lines * (tinv || quarter ? P : M));
+      const auto tiled_grid = [&](int64_t per) { return b.oneshot_grid((lines / S) * ((S + 31) / 32) * ((per + 31) / 32)); };   // one workgroup per tile
+      pre.grid = S > 1 ? tiled_grid(tinv || quarter ? P : M) : b.oneshot_grid((lines * (tinv || quarter ? P : M) + 255) / 256);   // streaming pass: one-shot grid (r02)
       b.ir.route += "trig-real[kind=" + std::to_string(kind) + "] ";
       const int rc = quarter ? b.emit_axis(V, V, M, 1, lines, false, 1.0f, err)
                    : tinv ? b.emit_c2r_even(V, v, M, lines, 1.0f, err) : b.emit_r2c_even(v, V, M, lines, 1.0f, err);
@@ -1335,7 +1336,7 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       post.p[0] = quarter ? cur : v; post.p[1] = V; post.p[2] = dst;
       post.i[0] = lines; post.i[1] = N; post.i[2] = P; post.i[3] = M; post.i[4] = rkind; post.i[5] = S;
       post.f[0] = last;
-      post.grid = S > 1 ? tiled_grid(tfwd || quarter ? P : N) : b.generic_grid(lines * (tfwd || quarter ? P : N));
+      post.grid = S > 1 ? tiled_grid(tfwd || quarter ? P : N) : b.oneshot_grid((lines * (tfwd || quarter ? P : N) + 255) / 256);
       b.work_top = mark;
       cur = dst;
       S *= N;
