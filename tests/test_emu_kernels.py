@@ -95,7 +95,7 @@ def test_c2c_generic_mixed_radix(oracle, monkeypatch, n, mixed):
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 2e-6 if n < 1000 else 1e-5)
 
 
-MIXED_CT = [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 120, 240, 480, 720, 1440]
+MIXED_CT = [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 500, 1500, 120, 240, 480, 720, 1440]
 
 
 @pytest.mark.parametrize("n", MIXED_CT)

@@ -246,7 +246,7 @@ def test_c2c_mixed_radix(fft, dev, oracle, monkeypatch, n, mixed):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"N={n} {direction} {route}", 3e-3, 3e-3)
 
 
-@pytest.mark.parametrize("n", [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 120, 240, 480, 720, 1440])
+@pytest.mark.parametrize("n", [96, 192, 384, 768, 1536, 3072, 160, 320, 640, 1280, 2560, 1000, 2000, 3000, 105, 1001, 360, 1920, 2187, 500, 1500, 120, 240, 480, 720, 1440])
 def test_c2c_mixed_radix_compile_time_plans(fft, dev, oracle, n):
     """every instance of kern_mixed_ct.hpp: radices, tile shape and threads as template constants (232 vs 85 GPoints/s at N=1000);
     batches with several tiles per workgroup and a ragged last tile, against the oracle's O(N^2) DFT"""

@@ -98,6 +98,13 @@ struct R2cPostArgs {
 // declared 8-byte aligned and the hardware splits nothing but the first and last line of a wave's 1 KiB run.  8-byte-per-lane
 // accesses moved this pass at 4.1 TB/s (profiles/r01_rocprof_r2c_2p22_kernel_stats.csv).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(8)));
+#if MI355_POST_NT
+#define MI_POST_LD4(p) __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p))
+#define MI_POST_ST4(p, v) __builtin_nontemporal_store((v), reinterpret_cast<f4u*>(p))
+#else
+#define MI_POST_LD4(p) (*reinterpret_cast<const f4u*>(p))
+#define MI_POST_ST4(p, v) (*reinterpret_cast<f4u*>(p) = (v))
+#endif
 // Work item = (line b, chunk of 256*U bin pairs): the divisions are wave-uniform (scalar), lanes walk k.
 // One lane forms X[k], X[k+1] and their mirrors X[H-k], X[H-k-1] from (Z[k], Z[k+1], Z[H-k-1], Z[H-k]), k = 0, 2, .. <= H/2, so every Z
 // is read once:   X[k] = E + w O,  X[H-k] = conj(E - w O),  E = (Z[k] + conj Z[H-k])/2,  O = -i (Z[k] - conj Z[H-k])/2,  w = e^{-2 pi i k/N}
@@ -130,7 +137,7 @@ static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs 
       // last pair of a line, lanes beyond the line) goes element by element below
       const bool full = k > 0 && 2 * (k + 1) < a.H;
       const long long kc = full ? k : 2;                                  // clamped lanes read somewhere harmless and in range
-      if (a.H >= 8) { za[j] = *reinterpret_cast<const f4u*>(z + kc); zb[j] = *reinterpret_cast<const f4u*>(z + (a.H - kc - 1)); }
+      if (a.H >= 8) { za[j] = MI_POST_LD4(z + kc); zb[j] = MI_POST_LD4(z + (a.H - kc - 1)); }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -143,8 +150,8 @@ static __global__ void __launch_bounds__(256) r2c_post_kernel(const R2cPostArgs 
         split(cf{za[j].x, za[j].y}, cf{zb[j].z, zb[j].w}, w0, x0, m0);                  // (Z[k],   Z[H-k])
         split(cf{za[j].z, za[j].w}, cf{zb[j].x, zb[j].y}, cmul(w0, w1), x1, m1);        // (Z[k+1], Z[H-k-1])
         const f4u up = {x0.x, x0.y, x1.x, x1.y}, dn = {m1.x, m1.y, m0.x, m0.y};
-        *reinterpret_cast<f4u*>(x + k) = up;
-        *reinterpret_cast<f4u*>(x + (a.H - k - 1)) = dn;
+        MI_POST_ST4(x + k, up);
+        MI_POST_ST4(x + (a.H - k - 1), dn);
       } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -199,7 +206,7 @@ static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a)
       const long long k = 2 * (p0 + j * 256);
       const bool full = k > 0 && 2 * (k + 1) < a.H;
       const long long kc = full ? k : 2;
-      if (a.H >= 8) { xa[j] = *reinterpret_cast<const f4u*>(x + kc); xb[j] = *reinterpret_cast<const f4u*>(x + (a.H - kc - 1)); }
+      if (a.H >= 8) { xa[j] = MI_POST_LD4(x + kc); xb[j] = MI_POST_LD4(x + (a.H - kc - 1)); }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -212,8 +219,8 @@ static __global__ void __launch_bounds__(256) c2r_pre_kernel(const C2rPreArgs a)
         merge(cf{xa[j].x, xa[j].y}, cf{xb[j].z, xb[j].w}, w0, z0, m0);                  // (X[k],   X[H-k])
         merge(cf{xa[j].z, xa[j].w}, cf{xb[j].x, xb[j].y}, cmul(w0, w1), z1, m1);        // (X[k+1], X[H-k-1])
         const f4u up = {z0.x, z0.y, z1.x, z1.y}, dn = {m1.x, m1.y, m0.x, m0.y};
-        *reinterpret_cast<f4u*>(z + k) = up;
-        *reinterpret_cast<f4u*>(z + (a.H - k - 1)) = dn;
+        MI_POST_ST4(z + k, up);
+        MI_POST_ST4(z + (a.H - k - 1), dn);
       } else {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
