@@ -31,12 +31,19 @@ def test_trig_1d(oracle, typ, n):
 
 @pytest.mark.parametrize("typ", TYPES)
 @pytest.mark.parametrize("n,fused,backend", [(4, "1", "r2c-split"), (100, "1", "r2c-split"), (256, "1", "lines-r2c"), (4096, "1", "lines-r2c"),
-                                             (4096, "2", "xcd-r2c")])
+                                             (4096, "2", "xcd-r2c"), (256, "1", "lines-dct2"), (4096, "1", "lines-dct2"), (8192, "1", "lines-dct2")])
 def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
     """dense axis 0 (kern_trig.hpp kinds 8..15): dct2/dst2/dct3/dst3 as Makhoul permutation + a real FFT of length N over each
     r2c / c2r back-end, dct4/dst4 as a complex FFT of N/2, dct1/dst1 as the r2c of the real extension; the general 2N route
     (MI355_EMU_TRIG_REAL=0) must agree with all of them"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", fused)
+    # backend "lines-dct2": the DCT-II / DST-II computation (dct2 / dst2 forward, dct3 / dst3 inverse) as ONE line-kernel launch —
+    # permutation in the LDS staging, real FFT, phase in the split (kern_lines.hpp fft_lines_r2c_kernel<C, TRIG>) — and the
+    # DCT-III / DST-III computation the same way on the c2r line kernel; the other back-ends run with that fusion off
+    one_launch = backend == "lines-dct2"
+    monkeypatch.setenv("MI355_EMU_TRIG_FUSED", "1" if one_launch else "0")
+    if one_launch and typ[3] in "14":
+        pytest.skip("DCT-II / DST-II computations only")
     if fused == "2":
         monkeypatch.setenv("MI355_EMU_CUS", "4")
         monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")
@@ -45,11 +52,15 @@ def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
     x = oracle.random_real_batch(n, batch, 0x7B16 + n).reshape(-1)
     for direction in ("forward", "inverse"):
         desc, _ = _desc({"type": typ, "shape": [n], "batch": batch, "direction": direction, "normalize": "unitary", "layout": {"interleavedComplex": False}})
-        got, route, _ = emu.run_plan(desc, x, x.size)
-        assert route.startswith("trig-real[") and "trig[" not in route, route
-        assert ("r2c" in route or "c2r" in route) == (typ[3] != "4"), route
-        if direction == "forward" and typ in ("dct2", "dst2"):
-            assert backend in route, route
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        is_type2 = (typ[3] == "2") == (direction == "forward")         # dct2 forward / dct3 inverse compute a DCT-II
+        if one_launch:
+            assert route.strip() == "lines-d%st%d[N=%d]" % (typ[1], 2 if is_type2 else 3, n) and launches == 1, route
+        else:
+            assert route.startswith("trig-real[") and "trig[" not in route, route
+            assert ("r2c" in route or "c2r" in route) == (typ[3] != "4"), route
+            if direction == "forward" and typ in ("dct2", "dst2"):
+                assert backend in route, route
         want = oracle.trig_ref_batch(x, [n], batch, typ, direction, "unitary")
         scale = max(1.0, float(np.max(np.abs(want))))
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 2e-5 * scale, (typ, n, direction, route)

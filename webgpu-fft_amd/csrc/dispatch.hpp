@@ -37,6 +37,10 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
           l.launch(fft_lines_r2c_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
         }                                                                                \
+        if (a.real_mode == 5 || a.real_mode == 6) {                                      \
+          l.launch(fft_lines_r2c_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          return true;                                                                   \
+        }                                                                                \
         if (a.real_mode == 4) {                                                          \
           l.launch(fft_lines_mul_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
@@ -46,6 +50,12 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
         if (a.real_mode == 2) {                                                          \
           l.launch(fft_lines_c2r_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
+        }                                                                                \
+        if constexpr (C::NSTAGES >= 2) {                                                 \
+          if (a.real_mode == 7 || a.real_mode == 8) {                                    \
+            l.launch(fft_lines_c2r_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+            return true;                                                                 \
+          }                                                                              \
         }                                                                                \
       }                                                                                  \
       if (a.real_mode != 0) return false;                                                \

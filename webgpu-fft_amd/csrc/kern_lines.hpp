@@ -461,7 +461,13 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
 // half-length trick (kern_generic.hpp r2c_post_kernel: X[k] = E + wO, X[H-k] = conj(E - wO)) is applied from there: one launch,
 // 4 B read + 4 B written per real point where the two-launch route moves 12.  a.out lines have H+1 bins (a.out_outer_stride);
 // roots e^{-2 pi i k/N} = tw_hi[k >> fs_shift] * tw_lo[k & fs_lo_mask].
-template <class C>
+//
+// TRIG (r02; dct_fft.js DCT-II / DST-II): the same kernel as a whole DCT-II (a.real_mode == 5) or DST-II (6) of real
+// lines of length N = 2H — Makhoul's permutation v[n] = x[2n], v[N-1-n] = x[2n+1] (DST-II: odd samples negated) is applied while
+// the line is staged into the LDS line buffer (pair loads from memory, float stores into LDS), the half-length FFT and the split
+// give V = r2c(v), and each bin leaves as two real outputs y[k] = Re t, y[N-k] = -Im t, t = e^{-i pi k/2N} V[k] (DST-II: the
+// output order reversed).  One launch and 8 B per point where the pre-pass + r2c + post-pass route moved 28.
+template <class C, bool TRIG = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
   MI_SMEM_DECL(smem);
@@ -472,10 +478,36 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
     for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
     __syncthreads();
   }
-  constexpr int H = C::N, PER = H / 2 + 1;
+  constexpr int H = C::N, PER = H / 2 + 1, NREAL = 2 * H;
+  const bool sine = TRIG && a.real_mode == 6;
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
-    stage_read<C, 0>(v, a, tile, t, lds);
+    if constexpr (TRIG) {
+      const long long G0 = tile * C::T;
+      const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
+      float* ldsf = reinterpret_cast<float*>(lds);
+      const float* xin = reinterpret_cast<const float*>(a.in);
+      for (int p = t; p < live * H; p += C::THREADS) {
+        const int l = p / H, n = p - l * H;
+        const cf pr = *reinterpret_cast<const cf*>(xin + (G0 + l) * (long long)NREAL + 2 * n);   // (x[2n], x[2n+1])
+        const int j1 = NREAL - 1 - n;
+        ldsf[2 * lds_index<C>(l, n >> 1) + (n & 1)] = pr.x;                      // v[n]     = x[2n]
+        ldsf[2 * lds_index<C>(l, j1 >> 1) + (j1 & 1)] = sine ? -pr.y : pr.y;     // v[N-1-n] = x[2n+1]
+      }
+      __syncthreads();
+      {
+        using I0 = StageInfo<C, 0>;
+        int line, u; thread_map<C, 0>(t, line, u);
+#pragma unroll
+        for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+          for (int q = 0; q < I0::R; ++q) v[b * I0::R + q] = lds[lds_index<C>(line, u + b * C::TPL + q * (H / I0::R))];
+        }
+      }
+      __syncthreads();   // everyone has its inputs before stage 0 re-uses the buffer
+    } else {
+      stage_read<C, 0>(v, a, tile, t, lds);
+    }
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
     __syncthreads();
     stage_read<C, 1>(v, a, tile, t, lds);
@@ -502,10 +534,28 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
       const cf xk = (e + wo) * a.scale;
       cf xm = (e - wo) * a.scale;
       xm.y = -xm.y;
-      cf* x = a.out + (G0 + line) * a.out_outer_stride;
-      x[k] = xk;
-      if (k == 0) x[H] = xm;
-      else if (km != k) x[km] = xm;
+      if constexpr (TRIG) {
+        float* y = reinterpret_cast<float*>(a.out) + (G0 + line) * (long long)NREAL;
+        const auto emit = [&](cf V, int m) {            // bin m of V = r2c(v) -> y[m] and y[N-m]
+          float sn, cs;
+#ifdef MI355_HOST_EMU
+          sn = (float)std::sin(-3.14159265358979323846 * (double)m / (2.0 * NREAL)); cs = (float)std::cos(3.14159265358979323846 * (double)m / (2.0 * NREAL));
+#else
+          sincospif(-(float)m / (float)(2 * NREAL), &sn, &cs);
+#endif
+          const float re = V.x * cs - V.y * sn, im = -(V.x * sn + V.y * cs);
+          y[sine ? NREAL - 1 - m : m] = re;
+          if (m > 0 && 2 * m != NREAL) y[sine ? m - 1 : NREAL - m] = im;
+        };
+        emit(xk, k);
+        if (k == 0) emit(xm, H);
+        else if (km != k) emit(xm, km);
+      } else {
+        cf* x = a.out + (G0 + line) * a.out_outer_stride;
+        x[k] = xk;
+        if (k == 0) x[H] = xm;
+        else if (km != k) x[km] = xm;
+      }
     }
     __syncthreads();   // LDS is re-used by the next tile
   }
@@ -567,9 +617,14 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 // imaginary parts of X[0] and X[H] are ignored, real_complex.js:147-155) is applied in LDS before the first stage (directly
 // in the first-stage loads for single-stage lines), and the unnormalised inverse of length H then lands x[2n] + i x[2n+1], i.e.
 // the real line, through the ordinary last-stage store.  C is the INVERSE ROW configuration (the swap trick of the c2c kernels).
-template <class C>
+//
+// TRIG (r02; DCT-III / DST-III, the inverses of the kernel above; a.real_mode == 7 / 8): the bins V[k] = (X[k] - i X[N-k]) e^{+i pi k/2N}/2
+// are formed from the REAL input line while the pre-split reads them (DST-III: the line reversed), and the finished real line is
+// un-permuted on its way out of the LDS line buffer: y[2n] = v[n], y[2n+1] = v[N-1-n] (DST-III: odd samples negated).
+template <class C, bool TRIG = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
+  static_assert(!TRIG || C::NSTAGES >= 2, "the fused DCT-III needs the LDS line buffer");
   MI_SMEM_DECL(smem);
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* tw_lds = lds + C::DATA_ELEMS;
@@ -579,6 +634,8 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
     __syncthreads();
   }
   constexpr int H = C::N;
+  [[maybe_unused]] constexpr int NREAL = 2 * H;
+  [[maybe_unused]] const bool sine = TRIG && a.real_mode == 8;
   using I0 = StageInfo<C, 0>;
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
@@ -595,9 +652,27 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         constexpr int PER = H / 2 + 1;
         for (int p = t; p < live * PER; p += C::THREADS) {
           const int l = p / PER, k = p - l * PER;
-          const cf* x = a.in + (G0 + l) * a.in_outer_stride;
           cf* xl = lds + l * C::PITCH;
-          cf pk = x[k], m = x[H - k];
+          cf pk, m;
+          if constexpr (TRIG) {
+            const float* X = reinterpret_cast<const float*>(a.in) + (G0 + l) * (long long)NREAL;
+            const auto bin = [&](int mm) {                 // V[mm] from the real line (trig_real_pre_kernel kinds 10 / 11)
+              const float re = sine ? X[NREAL - 1 - mm] : X[mm];
+              const float im = mm == 0 ? 0.0f : (sine ? X[mm - 1] : X[NREAL - mm]);
+              float sn, cs;
+#ifdef MI355_HOST_EMU
+              sn = (float)std::sin(3.14159265358979323846 * (double)mm / (2.0 * NREAL)); cs = (float)std::cos(3.14159265358979323846 * (double)mm / (2.0 * NREAL));
+#else
+              sincospif((float)mm / (float)(2 * NREAL), &sn, &cs);
+#endif
+              cf r; r.x = 0.5f * (re * cs + im * sn); r.y = 0.5f * (re * sn - im * cs);
+              return r;
+            };
+            pk = bin(k); m = bin(H - k);
+          } else {
+            const cf* x = a.in + (G0 + l) * a.in_outer_stride;
+            pk = x[k]; m = x[H - k];
+          }
           if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
           const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
           const cf mc = {m.x, -m.y};
@@ -637,13 +712,30 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
       lines_sync<C>();
       stage_read<C, 1>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 1>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 1, false, TRIG && C::NSTAGES == 2>(v, a, tile, t, lds, tw_lds, nullptr);
     }
     if constexpr (C::NSTAGES == 3) {
       lines_sync<C>();
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 2>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 2, false, TRIG>(v, a, tile, t, lds, tw_lds, nullptr);
+    }
+    if constexpr (TRIG) {
+      // the finished line sits in LDS as swapped pairs (v[2n+1], v[2n]) (the inverse runs on re/im-swapped data and the swap back
+      // belongs to the store): un-permute while storing — one float2 (y[2n], y[2n+1]) per lane
+      __syncthreads();
+      const long long G0 = tile * C::T;
+      const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
+      const float* ldsf = reinterpret_cast<const float*>(lds);
+      float* yout = reinterpret_cast<float*>(a.out);
+      for (int p = t; p < live * H; p += C::THREADS) {
+        const int l = p / H, n = p - l * H, j1 = NREAL - 1 - n;
+        const float v0 = ldsf[2 * lds_index<C>(l, n >> 1) + (1 - (n & 1))];
+        const float v1 = ldsf[2 * lds_index<C>(l, j1 >> 1) + (1 - (j1 & 1))];
+        cf o; o.x = v0 * a.scale; o.y = (sine ? -v1 : v1) * a.scale;
+        *reinterpret_cast<cf*>(yout + (G0 + l) * (long long)NREAL + 2 * n) = o;
+      }
+      __syncthreads();   // LDS is re-used by the next tile
     }
   }
 }

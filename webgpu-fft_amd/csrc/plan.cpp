@@ -129,6 +129,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_LINES_R2C")) o.lines_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_C2R")) o.lines_c2r = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_TRIG_REAL")) o.trig_real = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_TRIG_FUSED")) o.trig_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_CONV_LINES")) o.conv_lines = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_CONV_FUSED_MAX_POINTS")) { const long long v = std::atoll(s); if (v >= 0) o.conv_fused_max_points = v; }
   if (const char* s = std::getenv("MI355FFT_MAX_LINE")) { const int v = std::atoi(s); if (v >= 4096) o.max_line = v; }
@@ -367,7 +368,8 @@ struct Builder {
   // r2c of dense real lines of length N = 2H, H a power of two in 64..max_line: the ROW line kernel of length H with the split
   // fused behind its last stage (one launch instead of FFT + r2c_post_kernel)
   // (c2r: the mirror — the pre-split rides the first-stage loads of the INVERSE line kernel, any power-of-two half length >= 2)
-  bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false) {
+  // trig = 5 / 6: the same launch as a whole DCT-II / DST-II of the real lines (kern_lines.hpp fft_lines_r2c_kernel<C, TRIG>)
+  bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false, int trig = 0) {
     const int64_t H = N / 2;
     if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;
     if (c2r && H > 8192 && opt.lines_c2r != 2) return false;     // N = 2^15: the Hermitian four-step in solo mode measured faster (322 vs 304)   // xcd_fused == 2: emulation tests of the fused instances
@@ -381,10 +383,10 @@ struct Builder {
     st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m); st.p[3] = add_table(lo); st.p[4] = add_table(hi);
     const int64_t tiles = (lines + m->T - 1) / m->T;
     st.i[0] = tiles; st.i[1] = lines; st.i[2] = 1; st.i[3] = c2r ? H + 1 : H; st.i[4] = 1; st.i[5] = c2r ? H : H + 1; st.i[6] = 10; st.i[7] = 1023;
-    st.i[9] = c2r ? 2 : 1;
+    st.i[9] = trig ? trig : (c2r ? 2 : 1);
     st.f[0] = scale;
     st.grid = lines_grid(*m, tiles);
-    ir.route += std::string(c2r ? "lines-c2r[N=" : "lines-r2c[N=") + std::to_string(N) + "] ";
+    ir.route += std::string(trig == 5 ? "lines-dct2[N=" : trig == 6 ? "lines-dst2[N=" : trig == 7 ? "lines-dct3[N=" : trig == 8 ? "lines-dst3[N=" : c2r ? "lines-c2r[N=" : "lines-r2c[N=") + std::to_string(N) + "] ";
     return true;
   }
 
@@ -1318,6 +1320,19 @@ int build_trig(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       // length N/2 (dct4/dst4), or the r2c of the real even/odd extension (dct1/dst1) -- kern_trig.hpp kinds 8..15
       const bool tfwd = kind == 1 || kind == 5, tinv = kind == 2 || kind == 6, quarter = kind == 3 || kind == 7;
       const int rkind = tfwd ? (kind == 1 ? 8 : 9) : tinv ? (kind == 2 ? 10 : 11) : quarter ? (kind == 3 ? 12 : 13) : (kind == 0 ? 14 : 15);
+      // DCT-II / DST-II of dense lines whose half length is a line-kernel size: permutation, real FFT and phase in ONE launch
+      if (tfwd && S == 1 && b.opt.trig_fused && b.emit_lines_r2c(cur, dst, N, lines, a == rank - 1 ? scale : 1.0f, false, kind == 1 ? 5 : 6)) {
+        cur = dst;
+        S *= N;
+        continue;
+      }
+      // DCT-III / DST-III the same way on the c2r line kernel (bins formed from the real line in the pre-split, un-permutation
+      // in the store); needs the LDS line buffer: half lengths of 64 and more
+      if (tinv && S == 1 && N >= 128 && b.opt.trig_fused && b.emit_lines_r2c(cur, dst, N, lines, a == rank - 1 ? scale : 1.0f, true, kind == 2 ? 7 : 8)) {
+        cur = dst;
+        S *= N;
+        continue;
+      }
       const int64_t M = quarter ? N / 2 : (kind == 0 || kind == 4 ? L : N);     // length of the FFT in the middle
       const int64_t P = quarter ? M : M / 2 + 1;                                  // complex elements per line
       const PtrRef v = quarter ? PtrRef() : b.alloc_work((uint64_t)lines * M * 4), V = b.alloc_work((uint64_t)lines * P * 8);

@@ -153,6 +153,7 @@ struct PlannerOptions {
   int mixed_threads = 256;
   int64_t conv_fused_max_points = (int64_t)1 << 20;   // fftconv-fused (one launch, latency route) up to this many points B*N*K; above: forward-mul + inverse line launches
   int conv_lines = 1;                  // fftconv: kernel-spectrum product fused behind the forward line FFT (1-D, power-of-two FFT length <= max_line)
+  int trig_fused = 1;                  // dct2 / dst2 of dense lines (half length a line-kernel size): permutation + real FFT + phase in one launch
   int trig_real = 1;                   // dct2/dst2/dct3/dst3 along a dense even axis through a real FFT of length N (kern_trig.hpp)
   int lines_c2r = 1;                   // c2r twin (pair pre-split from global into LDS before the first stage): half lengths <= 8192
                                        // (N = 256: 528 vs 133 G real points/s, 1024: 471 vs 243, 2^14: 312 vs 270); 2 forces it at 2^15 too
