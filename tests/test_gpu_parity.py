@@ -718,8 +718,15 @@ def test_dct_dst_real_fft_route_long(fft, dev, oracle, monkeypatch, typ, lg):
     n, batch = (1 << lg) + {"dct1": 1, "dst1": -1}.get(typ, 0), 3       # dct1 / dst1: the extension 2(N -/+ 1) is the power of two
     x = oracle.random_real_batch(n, batch, 0x7C00 + lg).reshape(-1)
     opts = {"type": typ, "shape": [n], "batch": batch, "direction": "forward", "normalize": "none", "layout": {"interleavedComplex": False}}
-    got, (route, _) = run_plan(fft, dev, opts, x, x.size)
-    assert route.startswith("trig-real["), route
+    got, (route, launches) = run_plan(fft, dev, opts, x, x.size)
+    if lg == 13 and typ[3] in "23":       # half length 4096: the whole DCT-II / DCT-III (DST) is ONE line-kernel launch (r02)
+        assert route.strip() == "lines-%s[N=%d]" % (typ, n) and launches == 1, route
+        monkeypatch.setenv("MI355FFT_TRIG_FUSED", "0")
+        three, (route3, _) = run_plan(fft, dev, opts, x, x.size)
+        assert route3.startswith("trig-real["), route3
+        assert float(np.max(np.abs(got.astype(np.float64) - three.astype(np.float64)))) <= 2e-5 * float(np.sqrt(np.mean(three.astype(np.float64) ** 2))) * 8
+    else:
+        assert route.startswith("trig-real["), route
     monkeypatch.setenv("MI355FFT_TRIG_REAL", "0")
     old, (route0, _) = run_plan(fft, dev, opts, x, x.size)
     assert "trig-real" not in route0, route0

@@ -537,12 +537,8 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
       if constexpr (TRIG) {
         float* y = reinterpret_cast<float*>(a.out) + (G0 + line) * (long long)NREAL;
         const auto emit = [&](cf V, int m) {            // bin m of V = r2c(v) -> y[m] and y[N-m]
-          float sn, cs;
-#ifdef MI355_HOST_EMU
-          sn = (float)std::sin(-3.14159265358979323846 * (double)m / (2.0 * NREAL)); cs = (float)std::cos(3.14159265358979323846 * (double)m / (2.0 * NREAL));
-#else
-          sincospif(-(float)m / (float)(2 * NREAL), &sn, &cs);
-#endif
+          const cf ph = a.tw_lo[1024 + m];              // e^{-i pi m/2N}: f64-built table behind the LO roots (plan.cpp emit_lines_r2c)
+          const float cs = ph.x, sn = ph.y;
           const float re = V.x * cs - V.y * sn, im = -(V.x * sn + V.y * cs);
           y[sine ? NREAL - 1 - m : m] = re;
           if (m > 0 && 2 * m != NREAL) y[sine ? m - 1 : NREAL - m] = im;
@@ -659,12 +655,8 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
             const auto bin = [&](int mm) {                 // V[mm] from the real line (trig_real_pre_kernel kinds 10 / 11)
               const float re = sine ? X[NREAL - 1 - mm] : X[mm];
               const float im = mm == 0 ? 0.0f : (sine ? X[mm - 1] : X[NREAL - mm]);
-              float sn, cs;
-#ifdef MI355_HOST_EMU
-              sn = (float)std::sin(3.14159265358979323846 * (double)mm / (2.0 * NREAL)); cs = (float)std::cos(3.14159265358979323846 * (double)mm / (2.0 * NREAL));
-#else
-              sincospif((float)mm / (float)(2 * NREAL), &sn, &cs);
-#endif
+              const cf ph = a.tw_lo[1024 + mm];           // e^{-i pi m/2N} (table behind the LO roots); the phase wanted is its conjugate
+              const float cs = ph.x, sn = -ph.y;
               cf r; r.x = 0.5f * (re * cs + im * sn); r.y = 0.5f * (re * sn - im * cs);
               return r;
             };

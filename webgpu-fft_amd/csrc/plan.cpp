@@ -378,6 +378,8 @@ struct Builder {
     std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));
     for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
+    // trig: the DCT phases e^{-i pi m/2N} = e^{-2 pi i m/4N}, m = 0..N/2, f64-built, directly behind the 1024 LO roots (one table)
+    if (trig) for (int64_t mm = 0; mm <= H; ++mm) lo.push_back(root_of_unity(mm, 4 * N));
     Step& st = push(ST_LINES);
     st.variant = m->id;
     st.p[0] = src; st.p[1] = dst; st.p[2] = line_tables(*m); st.p[3] = add_table(lo); st.p[4] = add_table(hi);
