@@ -750,7 +750,7 @@ def test_dct_dst_nd_strided_axes(fft, dev, oracle, monkeypatch, typ):
         x = oracle.random_real_batch(n, batch, 0x7D00 + n).reshape(-1)
         opts = {"type": typ, "shape": shape, "batch": batch, "direction": "forward", "normalize": "backward", "layout": {"interleavedComplex": False}}
         got, (route, _) = run_plan(fft, dev, opts, x, x.size)
-        assert route.count("trig-real[") >= 2, route
+        assert route.count("trig-real[") + route.count("lines-d") >= 2, route
         want = oracle.trig_ref_batch(x, shape, batch, typ, "forward", "backward")
         assert float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * max(1.0, float(np.max(np.abs(want)))), (typ, shape, route)
     shape, batch = [1024, 512], 3
@@ -758,7 +758,7 @@ def test_dct_dst_nd_strided_axes(fft, dev, oracle, monkeypatch, typ):
     x = oracle.random_real_batch(n, batch, 0x7D77).reshape(-1)
     opts = {"type": typ, "shape": shape, "batch": batch, "direction": "forward", "normalize": "none", "layout": {"interleavedComplex": False}}
     got, (route, _) = run_plan(fft, dev, opts, x, x.size)
-    assert route.count("trig-real[") == 2, route
+    assert route.count("trig-real[") + route.count("lines-d") == 2, route   # axis 0 may be the one-launch DCT (lines-dct2 ...)
     monkeypatch.setenv("MI355FFT_TRIG_REAL", "0")
     old, (route0, _) = run_plan(fft, dev, opts, x, x.size)
     assert "trig-real" not in route0, route0
