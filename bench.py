@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "webgpu-fft_amd", "python"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
 ND_SHAPE = []   # set by an N-D probe workload
+LIN_KERNEL = []   # kernel length of a fftconvlin probe
 WORKLOADS = {
     # name: (type, N, batch per GPU, algorithmic bytes per point, description)
     "c2c_2p20_b4096": ("c2c", 1 << 20, 4096, 16, "1D c2c N=2^20 batch=4096 f32 forward, out-of-place (BASELINE config 3, north-star metric)"),
@@ -258,7 +259,12 @@ def main():
         import re
         m = re.fullmatch(r"(c2c|r2c|c2r|fftconv|dct[1-4]|dst[1-4])_(2p|n)(\d+)_b(\d+)", args.workload)
         nd = re.fullmatch(r"(c2c|r2c|dct[1-4]|dst[1-4])_s((?:\d+x)*\d+)_b(\d+)(_view)?", args.workload)      # N-D: axis 0 first; _view: padded read + cropped write
-        if nd:
+        lin = re.fullmatch(r"fftconvlin_n(\d+)k(\d+)_b(\d+)", args.workload)   # linear-full convolution, data n, kernel k (probe)
+        if lin:
+            WORKLOADS[args.workload] = ("fftconvlin", int(lin.group(1)), int(lin.group(3)), 16,
+                                        f"1D fftconv linear-full N={lin.group(1)} kernel={lin.group(2)} batch={lin.group(3)} (probe; NOT a BASELINE config)")
+            LIN_KERNEL[:] = [int(lin.group(2))]
+        elif nd:
             ND_SHAPE[:] = [int(v) for v in nd.group(2).split("x")]
             tot = 1
             for v in ND_SHAPE:
@@ -290,6 +296,11 @@ def main():
                 vn *= v
             in_bytes = out_bytes = vn * batch * 8
             in_row_floats = 2 * vn
+    elif typ == "fftconvlin":   # linear-full convolution: zero-padded embed of data and kernel, product, inverse, full output
+        kl = LIN_KERNEL[0]
+        in_bytes, out_bytes = n * batch * 8, (n + kl - 1) * batch * 8
+        in_row_floats = 2 * n
+        opts = {"type": "fftconv", "shape": [n], "batch": batch, "fftConv": {"mode": "convolution", "boundary": "linear-full", "kernelCount": 1, "kernelShape": [kl]}}
     elif typ == "fftconv":   # circular convolution with one full-length kernel (probe): forward FFTs, product, inverse FFT
         in_bytes = out_bytes = n * batch * 8
         in_row_floats = 2 * n
@@ -305,6 +316,18 @@ def main():
         in_bytes, out_bytes = n * batch * 4, packed * batch * 8
         in_row_floats = n
         opts = {"type": "r2c", "shape": shp, "batch": batch, "direction": "forward", "normalize": "none"}
+        if args.workload.endswith("_view"):   # as the c2c probe: padded read of a smaller real array, cropped write of the packed bins, zero ranges
+            pk = [shp[0] // 2 + 1] + shp[1:]
+            vin = [max(1, (v * 15) // 16) for v in shp]
+            vout = [max(1, (v * 15) // 16) for v in pk]
+            opts["ioView"] = {"input": {"shape": vin, "placement": "center"}, "output": {"shape": vout, "placement": "start"}}
+            opts["zeroPad"] = {"read": {"start": [1] * len(shp), "end": [v - 1 for v in shp]}, "write": {"start": [0] * len(shp), "end": [max(1, v - 2) for v in pk]}}
+            vi = vo = 1
+            for a_, b_ in zip(vin, vout):
+                vi *= a_
+                vo *= b_
+            in_bytes, out_bytes = vi * batch * 4, vo * batch * 8
+            in_row_floats = vi
     else:   # c2r probe: random packed spectra (not Hermitian-consistent in bins 0 and N/2; irrelevant for timing)
         in_bytes, out_bytes = (n // 2 + 1) * batch * 8, n * batch * 4
         in_row_floats = 2 * (n // 2 + 1)
@@ -323,9 +346,10 @@ def main():
     route, launches = plan.describe()
     enc = dev.createCommandEncoder()
     exec_args = {"input": inp, "output": out}
-    if typ == "fftconv":
-        kbuf = dev.createBuffer({"size": n * 8})
-        dev.fillRandom(kbuf, 0, 2 * n, 1, 0x5EED0004, 0)
+    if typ in ("fftconv", "fftconvlin"):
+        kn = n if typ == "fftconv" else LIN_KERNEL[0]
+        kbuf = dev.createBuffer({"size": kn * 8})
+        dev.fillRandom(kbuf, 0, 2 * kn, 1, 0x5EED0004, 0)
         exec_args["kernel"] = kbuf
     plan.exec(enc, exec_args)
     cmds = enc.finish()

@@ -159,10 +159,15 @@ def test_fftconv_fused_matches_composed_route_and_oracle(oracle, n, K, batch, mo
     ([12, 5], [3, 2], "linear-same", {"read": {"start": [1, 0], "end": [10, 5]}, "write": {"start": [2, 1], "end": [13, 5]}}),
     ([10], [4], "linear-valid", {"write": {"start": [0], "end": [8]}}),
     ([10], [4], "linear-full", {"write": {"start": [3], "end": [11]}}),
+    ([100], [29], "linear-full", {"read": {"start": [3], "end": [90]}, "write": {"start": [3], "end": [111]}}),       # FFT domain 128
+    ([30, 6], [3, 3], "linear-same", {"read": {"start": [1, 0], "end": [30, 5]}, "write": {"start": [2, 1], "end": [31, 8]}}),   # 32 x 8
 ])
-def test_fftconv_zero_pad(oracle, shape, kshape, boundary, zero_pad):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_fftconv_zero_pad(oracle, monkeypatch, shape, kshape, boundary, zero_pad, fuse):
     """zeroPad ranges live on the FFT domain (fftconv.js:353,386): read zeroes the embedded data before the forward
-    transform, write zeroes the inverse transform before the crop"""
+    transform, write zeroes the inverse transform before the crop.  fuse=1 (default): with a power-of-two FFT domain the embed, the
+    zero ranges and the crop are the address maps of the first forward / last inverse line-kernel launch"""
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fuse))
     batch, K, rank = 2, 2, len(shape)
     ks = kshape or shape
     n, kn = int(np.prod(shape)), int(np.prod(ks))
@@ -196,7 +201,11 @@ def test_fftconv_zero_pad(oracle, shape, kshape, boundary, zero_pad):
         want[:, :, ~keep] = 0
     got, route, _ = emu.run_plan(desc, x, 2 * on * K * batch, kernel=kern)
     assert not route.startswith("fftconv-fused")
-    assert ("zero-read" in route) == bool(zr) and ("zero-write" in route) == bool(zw), route
+    fs = list(shape) if boundary == "circular" else [s_ + k_ - 1 for s_, k_ in zip(shape, ks)]
+    if fuse and all(f & (f - 1) == 0 for f in fs):
+        assert "mapped[" in route and not [w for w in ("gather", "scatter", "zero-read", "zero-write") if w in route], route
+    else:
+        assert ("zero-read" in route) == bool(zr) and ("zero-write" in route) == bool(zw), route
     _close(got, want.reshape(-1), 4e-3, 4e-3, f"fftconv zeroPad {shape} {boundary}")
     assert oracle.rel_l2(got, want.reshape(-1)) < 1e-5
 
@@ -214,13 +223,15 @@ def test_fftconv_product_fused_into_forward_lines(oracle, monkeypatch, shape, ks
     desc, _ = _desc({"type": "fftconv", "shape": shape, "batch": batch,
                      "fftConv": {"mode": mode, "boundary": boundary, "kernelCount": K, "kernelShape": ks}})
     want = np.concatenate([oracle.fftconv_ref(x, kern[2 * k * kn:2 * (k + 1) * kn], shape, batch, mode, boundary, ks)[0] for k in range(K)])
-    got, route, _ = emu.run_plan(desc, x, want.size, kernel=kern)
-    assert "lines-mul[" in route, route
+    got, route, launches = emu.run_plan(desc, x, want.size, kernel=kern)
+    # linear modes: the zero-padded embed of kernels and data and the crop ride the launches too (kernel FFT, K x (forward-mul, inverse))
+    assert ("lines-mul-mapped[" if boundary != "circular" else "lines-mul[") in route, route
+    assert launches == 1 + 2 * K, route
     _close(got, want, 4e-3, 4e-3, route)
     assert oracle.rel_l2(got, want) < 1e-5, route
     monkeypatch.setenv("MI355_EMU_CONV_LINES", "0")
     old, route0, _ = emu.run_plan(desc, x, want.size, kernel=kern)
-    assert "lines-mul[" not in route0, route0
+    assert "lines-mul" not in route0, route0
     assert oracle.rel_l2(got, old) < 1e-6
 
 

@@ -240,11 +240,31 @@ REAL_CASES = [
     ([16], {"output": {"shape": [12], "placement": "center", "clearOutside": True}}, {"read": {"start": [3], "end": [13]}}),
     ([16, 4], {"input": {"shape": [12, 3], "offset": [1, 1]}}, {"write": {"start": [1, 0], "end": [8, 3]}}),
     ([64], None, {"read": {"start": [8], "end": [56]}, "write": {"start": [0], "end": [20]}}),
+    # line-kernel sizes: both sides ride the r2c line kernel (rank 1) / the r2c kernel and the last c2c axis (rank > 1)
+    ([128], {"input": {"shape": [100], "offset": [-5]}, "output": {"shape": [70], "offset": [-2]}}, {"read": {"start": [3], "end": [120]}, "write": {"start": [1], "end": [60]}}),
+    ([256, 4], {"input": {"shape": [200, 3], "offset": [10, 1]}, "output": {"shape": [140, 6], "offset": [-4, -1], "clearOutside": True}}, {"write": {"start": [0, 1], "end": [129, 4]}}),
+    ([128, 8, 2], None, {"read": {"start": [0, 1, 0], "end": [128, 7, 2]}}),
+    ([512], None, {"write": {"start": [0], "end": [100]}}),
 ]
+STAGING_WORDS = ("gather", "embed", "zero-read", "zero-write", "extract", "scatter")
 
 
+def _check_fused_route(route, launches, shape, fuse, clear):
+    """shape[0] >= 128 (a fused r2c / c2r line kernel exists): no staging launch with fusing on, one launch per axis"""
+    if shape[0] < 128:
+        return
+    staging = [w for w in STAGING_WORDS if w in route]
+    if fuse:
+        assert not staging and "mapped[" in route, route
+        assert launches == len([a for a in shape if a > 1]) + (1 if clear else 0), route
+    else:
+        assert staging and "mapped[" not in route, route
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("shape,io_view,zero_pad", REAL_CASES)
-def test_r2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
+def test_r2c_ioview_zeropad(oracle, monkeypatch, shape, io_view, zero_pad, fuse):
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fuse))
     batch = 2
     opts = {"type": "r2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "none"}
     if io_view:
@@ -259,7 +279,8 @@ def test_r2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
     x = oracle.random_real_batch(int(np.prod(in_shape)), batch, 4242 + sum(shape)).reshape(-1)
     out_floats = 2 * int(np.prod(out_shape)) * batch
     sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
-    got, route, _ = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    got, route, launches = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    _check_fused_route(route, launches, shape, fuse, bool((vout or {}).get("clearOutside")))
     logical = _embed(x, shape, vin, batch, 1)
     _zero_outside(logical, shape, r["zero_pad"]["read"])
     cplx = np.zeros((batch, *reversed(shape), 2), np.float32)
@@ -276,8 +297,14 @@ def test_r2c_ioview_zeropad(oracle, shape, io_view, zero_pad):
     ([16], {"output": {"shape": [10], "offset": [3]}}, None),
     ([16], {"input": {"shape": [6]}}, {"write": {"start": [2], "end": [14]}}),                  # low-pass: only the first 6 bins given
     ([16, 4], {"output": {"shape": [20, 4], "placement": "center", "clearOutside": True}}, {"read": {"start": [0, 0], "end": [5, 4]}}),
+    # line-kernel sizes: the packed side rides the first inverse c2c axis / the c2r kernel's loads, the real side its store pass
+    ([128], {"input": {"shape": [40]}, "output": {"shape": [100], "offset": [10]}}, {"write": {"start": [5], "end": [120]}}),
+    ([256, 4], {"output": {"shape": [300, 4], "placement": "center", "clearOutside": True}}, {"read": {"start": [0, 0], "end": [100, 4]}}),
+    ([128, 4, 2], {"input": {"shape": [60, 4, 2], "offset": [0, 0, 0]}}, None),
 ])
-def test_c2r_ioview_zeropad(oracle, shape, io_view, zero_pad):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_c2r_ioview_zeropad(oracle, monkeypatch, shape, io_view, zero_pad, fuse):
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fuse))
     batch = 2
     opts = {"type": "c2r", "shape": shape, "batch": batch, "direction": "inverse", "normalize": "backward"}
     if io_view:
@@ -306,7 +333,8 @@ def test_c2r_ioview_zeropad(oracle, shape, io_view, zero_pad):
         x = spec.reshape(-1)
     out_floats = int(np.prod(out_shape)) * batch
     sentinel = np.full(out_floats, 77.0, np.float32)
-    got, route, _ = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    got, route, launches = emu.run_plan(desc, x, out_floats, out_init=sentinel)
+    _check_fused_route(route, launches, shape, fuse, bool((vout or {}).get("clearOutside")))
     logical = _embed(x, packed, vin, batch, 2)
     _zero_outside(logical, packed, r["zero_pad"]["read"])
     p = packed[0]

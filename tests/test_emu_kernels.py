@@ -476,11 +476,13 @@ def test_support_kernels_match_oracle_prng(oracle):
     assert abs(s.value - float(np.sum(out.astype(np.float64) ** 2))) < 1e-9
 
 
-def test_r2c_c2r_whdcn_lanes(oracle):
+@pytest.mark.parametrize("n", [32, 256])
+def test_r2c_c2r_whdcn_lanes(oracle, n):
     """layout.whdcn on r2c / c2r: the real side and the packed side each resolve against their own physical shape
-    (docs/API.md "resolves per-side against the physical side shape"); only the addressed lane is read / written"""
+    (docs/API.md "resolves per-side against the physical side shape"); only the addressed lane is read / written.
+    n = 256: the lane addressing rides the r2c / c2r line kernels (one launch); n = 32: gather / scatter passes"""
     from mi355fft.layout import resolve_plan_options
-    n, batch, channels, cidx = 32, 2, 3, 1
+    batch, channels, cidx = 2, 3, 1
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 8800).reshape(-1)
     phys_in = np.full(batch * channels * n, 9.0, np.float32)
@@ -493,7 +495,7 @@ def test_r2c_c2r_whdcn_lanes(oracle):
     desc = _abi.make_desc("r2c", [n], batch, "forward", "none", input_layout=r["input_layout"], output_layout=r["output_layout"])
     sentinel = np.tile(np.array([77.0, -55.0], np.float32), batch * channels * p)
     got, route, _ = emu.run_plan(desc, phys_in, sentinel.size, out_init=sentinel)
-    assert "gather" in route and "scatter" in route
+    assert route.split() == ["lines-r2c-mapped[N=256]"] if n == 256 else ("gather" in route and "scatter" in route), route
     want = sentinel.copy()
     for b in range(batch):
         base = 2 * (b * channels * p + cidx * p)
@@ -505,6 +507,7 @@ def test_r2c_c2r_whdcn_lanes(oracle):
     desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward", input_layout=r["input_layout"], output_layout=r["output_layout"])
     rs = np.full(batch * channels * n, -3.0, np.float32)
     back, route, _ = emu.run_plan(desc, want, rs.size, out_init=rs)
+    assert route.split() == ["lines-c2r-mapped[N=256]"] if n == 256 else ("gather" in route and "scatter" in route), route
     wantr = rs.copy()
     for b in range(batch):
         wantr[b * channels * n + cidx * n: b * channels * n + (cidx + 1) * n] = x[b * n:(b + 1) * n]

@@ -332,22 +332,28 @@ def test_strided_layout_whdcn(fft, dev, oracle, n):
     check(oracle, got, want, "whdcn lanes")
 
 
-def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
     """views on the real transforms: the real side's window lives on the real domain, the spectrum side's on the packed one;
-    checked against the emu-tier numpy restatement (embed -> zero -> oracle -> zero -> extract)"""
+    checked against the emu-tier numpy restatement (embed -> zero -> oracle -> zero -> extract).  fuse=1: the sides ride the r2c / c2r
+    line kernels and the neighbouring c2c axis (no staging launch); fuse=0: the staging route"""
+    monkeypatch.setenv("MI355FFT_FUSE_VIEWS", str(fuse))
     from test_emu_ioview import _embed, _extract, _zero_outside
     from mi355fft.layout import resolve_plan_options
-    shape, batch = [256, 6], 3
-    packed = [129, 6]
+    shape, batch = [256, 8], 3
+    packed = [129, 8]
     opts = {"type": "r2c", "shape": shape, "batch": batch, "direction": "forward", "normalize": "none",
-            "ioView": {"input": {"shape": [200, 5], "offset": [20, 1]}, "output": {"shape": [140, 6], "offset": [-4, 0], "clearOutside": True}},
-            "zeroPad": {"read": {"start": [30, 0], "end": [210, 6]}, "write": {"start": [0, 0], "end": [100, 6]}}}
+            "ioView": {"input": {"shape": [200, 5], "offset": [20, 1]}, "output": {"shape": [140, 9], "offset": [-4, 0], "clearOutside": True}},
+            "zeroPad": {"read": {"start": [30, 0], "end": [210, 8]}, "write": {"start": [0, 1], "end": [100, 8]}}}
     r = resolve_plan_options(opts)
     x = oracle.random_real_batch(200 * 5, batch, 9911).reshape(-1)
-    out_floats = 2 * 140 * 6 * batch
+    out_floats = 2 * 140 * 9 * batch
     sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_floats // 2)
     got, (route, _) = run_plan(fft, dev, opts, x, out_floats, out_init=sentinel)
-    assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
+    if fuse:
+        assert route.split() == ["lines-r2c-mapped[N=256]", "columns-mapped[N=8,S=129]"], route
+    else:
+        assert "embed" in route and "extract" in route and "zero-read" in route and "zero-write" in route
     logical = _embed(x, shape, r["io_view"]["input"], batch, 1)
     _zero_outside(logical, shape, r["zero_pad"]["read"])
     cplx = np.zeros((batch, *reversed(shape), 2), np.float32)
@@ -365,6 +371,7 @@ def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle):
             "ioView": {"input": {"shape": [300]}, "output": {"shape": [5000], "offset": [-100]}}}
     sentinel = np.full(5000 * batch, 77.0, np.float32)
     got, (route, _) = run_plan(fft, dev, opts, low, 5000 * batch, out_init=sentinel)
+    assert route.split() == (["lines-c2r-mapped[N=4096]"] if fuse else ["embed", "lines-c2r[N=4096]", "extract"]), route
     lp = spec.copy()
     lp[:, 300:, :] = 0
     want = sentinel.reshape(batch, 5000).copy()
@@ -524,12 +531,12 @@ def test_fftconv_product_fused_into_forward_lines(fft, dev, oracle, monkeypatch,
     want = np.concatenate([oracle.fftconv_ref(x, kern[2 * k * kn:2 * (k + 1) * kn], shape, batch, mode, boundary, ks)[0] for k in range(K)])
     kernels = [kern[2 * k * kn:2 * (k + 1) * kn] for k in range(K)]
     got, (route, _) = run_plan(fft, dev, opts, x, want.size, kernel=kernels)
-    assert "lines-mul[" in route, route
+    assert ("lines-mul-mapped[" if boundary != "circular" else "lines-mul[") in route, route   # linear modes: embed and crop ride the launches
     check(oracle, got, want, route, 4e-3, 4e-3)
     assert oracle.rel_l2(got, want) < 1e-5, route
     monkeypatch.setenv("MI355FFT_CONV_LINES", "0")
     old, (route0, _) = run_plan(fft, dev, opts, x, want.size, kernel=kernels)
-    assert "lines-mul[" not in route0, route0
+    assert "lines-mul" not in route0, route0
     assert oracle.rel_l2(got, old) < 1e-6
 
 

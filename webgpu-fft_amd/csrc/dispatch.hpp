@@ -34,7 +34,8 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
       using C = LineCfg<N, R0, R1, R2, T, IC, OC, SI, SO, TW>;                           \
       if constexpr (!(IC) && !(OC) && !(SI) && !(SO) && (TW) == 0 && C::NSTAGES >= 2) {   \
         if (a.real_mode == 1) {                                                          \
-          l.launch(fft_lines_r2c_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          if (a.mapped) l.launch(fft_lines_r2c_kernel<C, false, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          else l.launch(fft_lines_r2c_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
         }                                                                                \
         if (a.real_mode == 5 || a.real_mode == 6) {                                      \
@@ -42,16 +43,21 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
           return true;                                                                   \
         }                                                                                \
         if (a.real_mode == 4) {                                                          \
-          l.launch(fft_lines_mul_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          if (a.mapped) l.launch(fft_lines_mul_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+          else l.launch(fft_lines_mul_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
         }                                                                                \
       }                                                                                  \
       if constexpr (!(IC) && !(OC) && (SI) && (SO) && (TW) == 0) {                        \
-        if (a.real_mode == 2) {                                                          \
+        if (a.real_mode == 2 && !a.mapped) {                                             \
           l.launch(fft_lines_c2r_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
           return true;                                                                   \
         }                                                                                \
         if constexpr (C::NSTAGES >= 2) {                                                 \
+          if (a.real_mode == 2) {                                                        \
+            l.launch(fft_lines_c2r_kernel<C, false, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
+            return true;                                                                 \
+          }                                                                              \
           if (a.real_mode == 7 || a.real_mode == 8) {                                    \
             l.launch(fft_lines_c2r_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
             return true;                                                                 \

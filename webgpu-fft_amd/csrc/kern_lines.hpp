@@ -467,9 +467,14 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
 // the line is staged into the LDS line buffer (pair loads from memory, float stores into LDS), the half-length FFT and the split
 // give V = r2c(v), and each bin leaves as two real outputs y[k] = Re t, y[N-k] = -Im t, t = e^{-i pi k/2N} V[k] (DST-II: the
 // output order reversed).  One launch and 8 B per point where the pre-pass + r2c + post-pass route moved 28.
-template <class C, bool TRIG = false>
+//
+// MAPPED (r02): the real side is read through a.imap (element = one float: strided layout, ioView.input box,
+// zeroPad.read range — zeros outside) and the packed bins leave through a.omap (ioView.output / zeroPad.write / strided layout of
+// the packed domain), as fft_lines_mapped_kernel does for c2c: no gather / embed / zero / extract / scatter launch around the r2c.
+template <class C, bool TRIG = false, bool MAPPED = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
+  static_assert(!(TRIG && MAPPED), "the fused DCT-II takes dense lines");
   MI_SMEM_DECL(smem);
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* tw_lds = lds + C::DATA_ELEMS;
@@ -505,6 +510,30 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
         }
       }
       __syncthreads();   // everyone has its inputs before stage 0 re-uses the buffer
+    } else if constexpr (MAPPED) {
+      using I0 = StageInfo<C, 0>;
+      const SideMap& im = a.imap;
+      int line, u; thread_map<C, 0>(t, line, u);
+      long long base = 0; bool zero;
+      const bool ok = side_line(im, tile * C::T + line, a.num_lines, base, zero);
+      const long long sa = im.stride[im.ax];
+      const int lo = im.lo[im.ax], hi = im.hi[im.ax];
+      const float* xin = reinterpret_cast<const float*>(a.in);
+      const bool pairs = ok && sa == 1 && (base & 1) == 0;
+#pragma unroll
+      for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < I0::R; ++q) {
+          const int j = 2 * (u + b * C::TPL + q * (H / I0::R));     // z[n] = x[2n] + i x[2n+1]
+          cf x = {0.0f, 0.0f};
+          if (pairs && j >= lo && j + 1 < hi) x = *reinterpret_cast<const cf*>(xin + base + j);   // unit stride, even base: one 8-byte load
+          else {
+            if (ok && j >= lo && j < hi) x.x = xin[base + (long long)j * sa];
+            if (ok && j + 1 >= lo && j + 1 < hi) x.y = xin[base + (long long)(j + 1) * sa];
+          }
+          v[b * I0::R + q] = x;
+        }
+      }
     } else {
       stage_read<C, 0>(v, a, tile, t, lds);
     }
@@ -522,8 +551,12 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
     __syncthreads();
     const long long G0 = tile * C::T;
     const int live = (int)((a.num_lines - G0) < (long long)C::T ? (a.num_lines - G0) : (long long)C::T);
-    for (int p = t; p < live * PER; p += C::THREADS) {
-      const int line = p / PER, k = p - line * PER;
+    // MAPPED: a thread stays on one line (its box test and base are computed once); otherwise the pairs are dealt out flat
+    [[maybe_unused]] long long obase = 0;
+    [[maybe_unused]] bool ozero = false, oline = false;
+    if constexpr (MAPPED) oline = side_line(a.omap, G0 + t / C::TPL, a.num_lines, obase, ozero);
+    for (int p = MAPPED ? t % C::TPL : t; p < (MAPPED ? PER : live * PER); p += MAPPED ? C::TPL : C::THREADS) {
+      const int line = MAPPED ? t / C::TPL : p / PER, k = MAPPED ? p : p - line * PER;
       const int km = k == 0 ? 0 : H - k;
       const cf zk = lds[lds_index<C>(line, k)], zm0 = lds[lds_index<C>(line, km)];
       const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
@@ -553,6 +586,16 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
         emit(xk, k);
         if (k == 0) emit(xm, H);
         else if (km != k) emit(xm, km);
+      } else if constexpr (MAPPED) {
+        const SideMap& om = a.omap;
+        const auto put = [&](int kk, cf val) {
+          if (!oline || kk < om.lo[om.ax] || kk >= om.hi[om.ax]) return;
+          if (ozero || kk < om.zlo[om.ax] || kk >= om.zhi[om.ax]) val = cf{0.0f, 0.0f};
+          a.out[obase + (long long)kk * om.stride[om.ax]] = val;
+        };
+        put(k, xk);
+        if (k == 0) put(H, xm);
+        else if (km != k) put(km, xm);
       } else {
         cf* x = a.out + (G0 + line) * a.out_outer_stride;
         x[k] = xk;
@@ -567,7 +610,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
 // fftconv, first half (src/kernels/fft_conv.js:3-66 pointwise product): forward FFT of complex lines whose
 // outputs are multiplied by the kernel spectrum a.tw_lo[k] (its conjugate when a.fs_shift != 0: correlation) as they are stored —
 // the separate pointwise pass (8 B read + 8 B written per point) disappears.  One spectrum for every line.
-template <class C>
+// MAPPED (r02): the data lines are read through a.imap (strided lanes, the zero-padded embed of the linear modes, zeroPad.read) —
+// fft_lines_mapped_kernel's first-stage loads — so that no gather / embed pass runs ahead of the product.
+template <class C, bool MAPPED = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
   MI_SMEM_DECL(smem);
@@ -598,7 +643,27 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
   }
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
-    stage_read<C, 0>(v, a, tile, t, lds);
+    if constexpr (MAPPED) {
+      using I0 = StageInfo<C, 0>;
+      const SideMap& im = a.imap;
+      int line, u; thread_map<C, 0>(t, line, u);
+      long long base = 0; bool zero;
+      const bool ok = side_line(im, tile * C::T + line, a.num_lines, base, zero);
+      const long long sa = im.stride[im.ax];
+      const int lo = im.lo[im.ax], hi = im.hi[im.ax];
+#pragma unroll
+      for (int b = 0; b < I0::NB; ++b) {
+#pragma unroll
+        for (int q = 0; q < I0::R; ++q) {
+          const int idx = u + b * C::TPL + q * (C::N / I0::R);
+          cf x = {0.0f, 0.0f};
+          if (ok && idx >= lo && idx < hi) x = a.in[base + (long long)idx * sa];
+          v[b * I0::R + q] = x;
+        }
+      }
+    } else {
+      stage_read<C, 0>(v, a, tile, t, lds);
+    }
     stage_compute_write<C, 0>(v, a, tile, t, lds, tw_lds, nullptr);
     lines_sync<C>();
     stage_read<C, 1>(v, a, tile, t, lds);
@@ -624,10 +689,14 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 // TRIG (r02; DCT-III / DST-III, the inverses of the kernel above; a.real_mode == 7 / 8): the bins V[k] = (X[k] - i X[N-k]) e^{+i pi k/2N}/2
 // are formed from the REAL input line while the pre-split reads them (DST-III: the line reversed), and the finished real line is
 // un-permuted on its way out of the LDS line buffer: y[2n] = v[n], y[2n+1] = v[N-1-n] (DST-III: odd samples negated).
-template <class C, bool TRIG = false>
+//
+// MAPPED (r02): the packed bins are read through a.imap (zeros outside its box) and the real line leaves the
+// LDS line buffer through a.omap (element = one float), as in the r2c kernel above.
+template <class C, bool TRIG = false, bool MAPPED = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
-  static_assert(!TRIG || C::NSTAGES >= 2, "the fused DCT-III needs the LDS line buffer");
+  static_assert(!(TRIG || MAPPED) || C::NSTAGES >= 2, "the fused DCT-III and the mapped sides need the LDS line buffer");
+  static_assert(!(TRIG && MAPPED), "the fused DCT-III takes dense lines");
   MI_SMEM_DECL(smem);
   cf* lds = reinterpret_cast<cf*>(smem);
   cf* tw_lds = lds + C::DATA_ELEMS;
@@ -653,32 +722,62 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         // the first stage then picks its inputs up
         static_assert(C::PITCH >= H + 1, "a packed line fits a line slot");
         constexpr int PER = H / 2 + 1;
-        for (int p = t; p < live * PER; p += C::THREADS) {
-          const int l = p / PER, k = p - l * PER;
-          cf* xl = lds + l * C::PITCH;
-          cf pk, m;
-          if constexpr (TRIG) {
-            const float* X = reinterpret_cast<const float*>(a.in) + (G0 + l) * (long long)NREAL;
-            const auto bin = [&](int mm) {                 // V[mm] from the real line (trig_real_pre_kernel kinds 10 / 11)
-              const float re = sine ? X[NREAL - 1 - mm] : X[mm];
-              const float im = mm == 0 ? 0.0f : (sine ? X[mm - 1] : X[NREAL - mm]);
-              const cf ph = a.tw_lo[1024 + mm];           // e^{-i pi m/2N} (table behind the LO roots); the phase wanted is its conjugate
-              const float cs = ph.x, sn = -ph.y;
-              cf r; r.x = 0.5f * (re * cs + im * sn); r.y = 0.5f * (re * sn - im * cs);
-              return r;
-            };
-            pk = bin(k); m = bin(H - k);
-          } else {
-            const cf* x = a.in + (G0 + l) * a.in_outer_stride;
-            pk = x[k]; m = x[H - k];
+        [[maybe_unused]] long long ibase = 0;
+        [[maybe_unused]] bool izero = false, iline = false;
+        if constexpr (MAPPED) iline = side_line(a.imap, G0 + t / C::TPL, a.num_lines, ibase, izero);
+        // the pairs are taken in batches of PU: all of a batch's loads (two bins and two root factors per pair) are issued before
+        // the first is used — one pair per iteration left the loop waiting out a full memory latency per pair
+        constexpr int PU = 4;
+        const int pend = MAPPED ? PER : live * PER, pstep = MAPPED ? C::TPL : C::THREADS;
+        for (int p0 = MAPPED ? t % C::TPL : t; p0 < pend; p0 += PU * pstep) {
+          cf pks[PU], ms[PU], whs[PU], wls[PU];
+#pragma unroll
+          for (int j = 0; j < PU; ++j) {
+            const int p = p0 + j * pstep;
+            if (p >= pend) break;
+            const int l = MAPPED ? t / C::TPL : p / PER, k = MAPPED ? p : p - l * PER;
+            cf pk, m;
+            if constexpr (MAPPED) {
+              const SideMap& im = a.imap;
+              const auto bin = [&](int kk) {
+                cf r = {0.0f, 0.0f};
+                if (iline && kk >= im.lo[im.ax] && kk < im.hi[im.ax]) r = a.in[ibase + (long long)kk * im.stride[im.ax]];
+                return r;
+              };
+              pk = bin(k); m = bin(H - k);
+            } else if constexpr (TRIG) {
+              const float* X = reinterpret_cast<const float*>(a.in) + (G0 + l) * (long long)NREAL;
+              const auto bin = [&](int mm) {                 // V[mm] from the real line (trig_real_pre_kernel kinds 10 / 11)
+                const float re = sine ? X[NREAL - 1 - mm] : X[mm];
+                const float im = mm == 0 ? 0.0f : (sine ? X[mm - 1] : X[NREAL - mm]);
+                const cf ph = a.tw_lo[1024 + mm];           // e^{-i pi m/2N} (table behind the LO roots); the phase wanted is its conjugate
+                const float cs = ph.x, sn = -ph.y;
+                cf r; r.x = 0.5f * (re * cs + im * sn); r.y = 0.5f * (re * sn - im * cs);
+                return r;
+              };
+              pk = bin(k); m = bin(H - k);
+            } else {
+              const cf* x = a.in + (G0 + l) * a.in_outer_stride;
+              pk = x[k]; m = x[H - k];
+            }
+            pks[j] = pk; ms[j] = m;
+            whs[j] = a.tw_hi[(unsigned)k >> a.fs_shift]; wls[j] = a.tw_lo[(unsigned)k & a.fs_lo_mask];
           }
-          if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
-          const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
-          const cf mc = {m.x, -m.y};
-          const cf e = pk + mc;
-          const cf o = cmul_conj(pk - mc, w);
-          xl[k] = e + mul_pos_i(o);
-          if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
+#pragma unroll
+          for (int j = 0; j < PU; ++j) {
+            const int p = p0 + j * pstep;
+            if (p >= pend) break;
+            const int l = MAPPED ? t / C::TPL : p / PER, k = MAPPED ? p : p - l * PER;
+            cf* xl = lds + l * C::PITCH;
+            cf pk = pks[j], m = ms[j];
+            if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
+            const cf w = cmul(whs[j], wls[j]);
+            const cf mc = {m.x, -m.y};
+            const cf e = pk + mc;
+            const cf o = cmul_conj(pk - mc, w);
+            xl[k] = e + mul_pos_i(o);
+            if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
+          }
         }
         __syncthreads();
         const cf* zl = lds + lclamp * C::PITCH;
@@ -711,13 +810,37 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
       lines_sync<C>();
       stage_read<C, 1>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 1, false, TRIG && C::NSTAGES == 2>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 1, false, (TRIG || MAPPED) && C::NSTAGES == 2>(v, a, tile, t, lds, tw_lds, nullptr);
     }
     if constexpr (C::NSTAGES == 3) {
       lines_sync<C>();
       stage_read<C, 2>(v, a, tile, t, lds);
       lines_sync<C>();
-      stage_compute_write<C, 2, false, TRIG>(v, a, tile, t, lds, tw_lds, nullptr);
+      stage_compute_write<C, 2, false, TRIG || MAPPED>(v, a, tile, t, lds, tw_lds, nullptr);
+    }
+    if constexpr (MAPPED) {
+      // the finished line sits in LDS as swapped pairs (x[2n+1], x[2n]); a thread stays on one line and walks it through omap
+      __syncthreads();
+      const SideMap& om = a.omap;
+      const int line = t / C::TPL, u = t % C::TPL;
+      long long base = 0; bool zero;
+      if (side_line(om, tile * C::T + line, a.num_lines, base, zero)) {
+        float* y = reinterpret_cast<float*>(a.out);
+        const long long so = om.stride[om.ax];
+        const int slo = om.lo[om.ax], shi = om.hi[om.ax], zlo = om.zlo[om.ax], zhi = om.zhi[om.ax];
+        const bool pairs = so == 1 && (base & 1) == 0;
+        for (int idx = u; idx < H; idx += C::TPL) {
+          const cf r = lds[lds_index<C>(line, idx)] * a.scale;
+          const int j = 2 * idx;
+          const float y0 = (zero || j < zlo || j >= zhi) ? 0.0f : r.y, y1 = (zero || j + 1 < zlo || j + 1 >= zhi) ? 0.0f : r.x;
+          if (pairs && j >= slo && j + 1 < shi) *reinterpret_cast<cf*>(y + base + j) = cf{y0, y1};   // unit stride, even base: one 8-byte store
+          else {
+            if (j >= slo && j < shi) y[base + (long long)j * so] = y0;
+            if (j + 1 >= slo && j + 1 < shi) y[base + (long long)(j + 1) * so] = y1;
+          }
+        }
+      }
+      __syncthreads();   // LDS is re-used by the next tile
     }
     if constexpr (TRIG) {
       // the finished line sits in LDS as swapped pairs (v[2n+1], v[2n]) (the inverse runs on re/im-swapped data and the swap back

@@ -369,12 +369,22 @@ struct Builder {
   // fused behind its last stage (one launch instead of FFT + r2c_post_kernel)
   // (c2r: the mirror — the pre-split rides the first-stage loads of the INVERSE line kernel, any power-of-two half length >= 2)
   // trig = 5 / 6: the same launch as a whole DCT-II / DST-II of the real lines (kern_lines.hpp fft_lines_r2c_kernel<C, TRIG>)
-  bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false, int trig = 0) {
+  // im / om (optional, both or none): the launch reads its input side through im and writes through om (fft_lines_r2c_kernel /
+  // fft_lines_c2r_kernel <.., MAPPED>; the real side's map counts floats, the packed side's complex bins)
+  const LineKernelMeta* lines_r2c_kernel(int64_t N, bool c2r, bool mapped) const {
     const int64_t H = N / 2;
-    if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;
-    if (c2r && H > 8192 && opt.lines_c2r != 2) return false;     // N = 2^15: the Hermitian four-step in solo mode measured faster (322 vs 304)   // xcd_fused == 2: emulation tests of the fused instances
+    if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return nullptr;
+    if (c2r && H > 8192 && opt.lines_c2r != 2 && !mapped) return nullptr;     // N = 2^15: the Hermitian four-step in solo mode measured faster (322 vs 304)   // xcd_fused == 2: emulation tests of the fused instances
     const LineKernelMeta* m = find_line_kernel((int)H, false, false, c2r, c2r, 0);
-    if (!m || (!c2r && m->lds_bytes == 0)) return false;
+    if (!m || (!c2r && m->lds_bytes == 0)) return nullptr;
+    if (mapped && (!opt.fuse_views || m->lds_bytes == 0 || m->R1 <= 1)) return nullptr;   // the mapped forms keep the line in LDS
+    return m;
+  }
+  bool emit_lines_r2c(PtrRef src, PtrRef dst, int64_t N, int64_t lines, float scale, bool c2r = false, int trig = 0,
+                      const SideMap* im = nullptr, const SideMap* om = nullptr) {
+    const int64_t H = N / 2;
+    const LineKernelMeta* m = lines_r2c_kernel(N, c2r, im != nullptr);
+    if (!m) return false;
     std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));
     for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
@@ -388,6 +398,11 @@ struct Builder {
     st.i[9] = trig ? trig : (c2r ? 2 : 1);
     st.f[0] = scale;
     st.grid = lines_grid(*m, tiles);
+    if (im) {
+      st.i[10] = 1; st.imap = *im; st.omap = *om; st.imap.ax = st.omap.ax = 0;
+      ir.route += std::string(c2r ? "lines-c2r-mapped[N=" : "lines-r2c-mapped[N=") + std::to_string(N) + "] ";
+      return true;
+    }
     ir.route += std::string(trig == 5 ? "lines-dct2[N=" : trig == 6 ? "lines-dst2[N=" : trig == 7 ? "lines-dct3[N=" : trig == 8 ? "lines-dst3[N=" : c2r ? "lines-c2r[N=" : "lines-r2c[N=") + std::to_string(N) + "] ";
     return true;
   }
@@ -986,6 +1001,53 @@ int validate_views(const mi355fft_plan_desc& d, std::string& err, const int64_t*
   return MI355FFT_OK;
 }
 
+// ---- a side of a plan as an address map over its logical domain (kern_lines.hpp side_line) ----
+// Input side: element i of the logical domain `lshape` is read at offset + sum (i_d - viewOffset_d) * stride_d inside the box where
+// the ioView.input window, the logical domain and the zeroPad.read range meet, and is zero elsewhere.
+SideMap input_side_map(const mi355fft_plan_desc& d, const int64_t* lshape, int rank) {
+  const bool vin = d.io_input.enabled != 0;
+  const int64_t* ishape = vin ? d.io_input.shape : lshape;
+  SideMap m = Builder::dense_map(lshape, rank);
+  int64_t dense = 1;
+  for (int i = 0; i < rank; ++i) {
+    m.stride[i] = d.input.strided ? d.input.strides[i] : dense;
+    dense *= ishape[i];
+    const int64_t voff = vin ? d.io_input.offset[i] : 0;
+    int64_t lo = std::max<int64_t>(0, voff), hi = vin ? std::min<int64_t>(lshape[i], voff + d.io_input.shape[i]) : lshape[i];
+    if (d.zero_read.enabled) { lo = std::max(lo, d.zero_read.start[i]); hi = std::min(hi, d.zero_read.end[i]); }
+    if (hi < lo) hi = lo;
+    m.lo[i] = (int)lo; m.hi[i] = (int)hi;
+    m.offset -= voff * m.stride[i];
+  }
+  m.offset += d.input.strided ? d.input.offset_elements : 0;
+  m.batch_stride = d.input.strided && d.input.batch_stride_elements > 0 ? d.input.batch_stride_elements : dense;
+  return m;
+}
+// Output side: element i is written inside the ioView.output window only, as zero outside the zeroPad.write range.
+SideMap output_side_map(const mi355fft_plan_desc& d, const int64_t* lshape, int rank) {
+  const bool vout = d.io_output.enabled != 0;
+  const int64_t* oshape = vout ? d.io_output.shape : lshape;
+  SideMap m = Builder::dense_map(lshape, rank);
+  int64_t dense = 1;
+  for (int i = 0; i < rank; ++i) {
+    m.stride[i] = d.output.strided ? d.output.strides[i] : dense;
+    dense *= oshape[i];
+    const int64_t voff = vout ? d.io_output.offset[i] : 0;
+    int64_t lo = std::max<int64_t>(0, voff), hi = vout ? std::min<int64_t>(lshape[i], voff + d.io_output.shape[i]) : lshape[i];
+    if (hi < lo) hi = lo;
+    m.lo[i] = (int)lo; m.hi[i] = (int)hi;
+    if (d.zero_write.enabled) { m.zlo[i] = (int)d.zero_write.start[i]; m.zhi[i] = (int)d.zero_write.end[i]; }
+    m.offset -= voff * m.stride[i];
+  }
+  m.offset += d.output.strided ? d.output.offset_elements : 0;
+  m.batch_stride = d.output.strided && d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : dense;
+  return m;
+}
+uint64_t side_bytes(const mi355fft_side_layout& lay, const mi355fft_io_view& view, const int64_t* lshape, int rank, int64_t batch, int64_t elem) {
+  const int64_t* pshape = view.enabled ? view.shape : lshape;
+  return lay.strided ? strided_extent_elems(lay, pshape, rank, batch, 0) * elem : (uint64_t)prodv(pshape, rank) * batch * elem;
+}
+
 // ---- the two sides of an r2c / c2r plan (the same staging build_c2c does inline, for real or complex elements) ----
 // Input: strided layout, ioView.input (embed into the zero-filled logical domain) and zeroPad.read produce a dense logical
 // array in the workspace; a plain dense input is used where it lies.  `phys_n`: elements of one physical item.
@@ -1103,38 +1165,8 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   const bool fuse_in = need_in && small && fa >= 0 && b.axis_mappable(d.shape[fa], stride_below(fa), inverse);
   const bool fuse_out = need_out && small && la >= 0 && b.axis_mappable(d.shape[la], stride_below(la), inverse);
   SideMap imap, omap;
-  if (fuse_in) {
-    imap = Builder::dense_map(d.shape, rank);
-    int64_t dense = 1;
-    for (int i = 0; i < rank; ++i) {
-      imap.stride[i] = d.input.strided ? d.input.strides[i] : dense;
-      dense *= ishape[i];
-      const int64_t voff = vin ? d.io_input.offset[i] : 0;
-      int64_t lo = std::max<int64_t>(0, voff), hi = vin ? std::min<int64_t>(d.shape[i], voff + d.io_input.shape[i]) : d.shape[i];
-      if (d.zero_read.enabled) { lo = std::max(lo, d.zero_read.start[i]); hi = std::min(hi, d.zero_read.end[i]); }
-      if (hi < lo) hi = lo;
-      imap.lo[i] = (int)lo; imap.hi[i] = (int)hi;
-      imap.offset -= voff * imap.stride[i];
-    }
-    imap.offset += d.input.strided ? d.input.offset_elements : 0;
-    imap.batch_stride = d.input.strided && d.input.batch_stride_elements > 0 ? d.input.batch_stride_elements : in_n;
-  }
-  if (fuse_out) {
-    omap = Builder::dense_map(d.shape, rank);
-    int64_t dense = 1;
-    for (int i = 0; i < rank; ++i) {
-      omap.stride[i] = d.output.strided ? d.output.strides[i] : dense;
-      dense *= oshape[i];
-      const int64_t voff = vout ? d.io_output.offset[i] : 0;
-      int64_t lo = std::max<int64_t>(0, voff), hi = vout ? std::min<int64_t>(d.shape[i], voff + d.io_output.shape[i]) : d.shape[i];
-      if (hi < lo) hi = lo;
-      omap.lo[i] = (int)lo; omap.hi[i] = (int)hi;
-      if (d.zero_write.enabled) { omap.zlo[i] = (int)d.zero_write.start[i]; omap.zhi[i] = (int)d.zero_write.end[i]; }
-      omap.offset -= voff * omap.stride[i];
-    }
-    omap.offset += d.output.strided ? d.output.offset_elements : 0;
-    omap.batch_stride = d.output.strided && d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : out_n;
-  }
+  if (fuse_in) imap = input_side_map(d, d.shape, rank);
+  if (fuse_out) omap = output_side_map(d, d.shape, rank);
 
   // ---- input side: dense logical staging when anything but a plain dense read is asked for and the first pass cannot map it ----
   PtrRef src = in;
@@ -1213,10 +1245,39 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   pshape[0] = P;
   // ioView.input / zeroPad.read live on the real logical domain, ioView.output / zeroPad.write on the packed one (r2c.js:72-123)
   if (int rv = validate_views(d, err, d.shape, pshape)) return rv;
-  const PtrRef user_out(BUF_OUTPUT, 0);
-  PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), d.shape, true, b.ir.in_bytes);
-  PtrRef out = side_output_target(d, b, user_out, pshape, false, b.ir.out_bytes);
-  if (N % 2 == 0) {
+  const PtrRef user_in(BUF_INPUT, 0), user_out(BUF_OUTPUT, 0);
+  const int rank = d.rank;
+  // ---- sides fused into the launches: the real side rides the r2c line kernel's first loads, the packed
+  // side its store pass (rank 1) or the store pass of the last c2c axis (rank > 1); whatever cannot be mapped is staged as before
+  const bool need_in = d.input.strided || d.io_input.enabled || d.zero_read.enabled;
+  const bool need_out = d.output.strided || d.io_output.enabled || d.zero_write.enabled;
+  const uint32_t upper = rank > 1 ? (((uint32_t)1 << rank) - 1u) & ~1u : 0u;
+  int fa = -1, la = -1;
+  if (rank > 1) Builder::nd_first_last(pshape, rank, upper, fa, la);
+  const bool small = n * 2 < ((int64_t)1 << 31);
+  const bool lines0 = small && b.lines_r2c_kernel(N, false, true) != nullptr;     // axis 0 can be the mapped line kernel
+  const auto stride_below = [&](int a) { int64_t S = 1; for (int i = 0; i < a; ++i) S *= pshape[i]; return S; };
+  const bool fuse_in = need_in && lines0;
+  const bool fuse_out = need_out && small && (la >= 1 ? b.axis_mappable(pshape[la], stride_below(la), false) : lines0);
+  if (fuse_out && d.io_output.enabled && d.io_output.clear_outside && d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
+  const bool map0 = fuse_in || (fuse_out && la < 1);                              // the axis-0 launch carries at least one map
+  b.ir.out_bytes = side_bytes(d.output, d.io_output, pshape, rank, d.batch, 8);
+  PtrRef in = user_in;
+  if (fuse_in) b.ir.in_bytes = side_bytes(d.input, d.io_input, d.shape, rank, d.batch, 4);
+  else in = stage_side_input(d, b, user_in, d.shape, true, b.ir.in_bytes);
+  // the dense packed array the passes work on: the caller's output unless a strided layout / ioView follows (staged or mapped)
+  PtrRef out = (d.output.strided || d.io_output.enabled) ? b.alloc_work((uint64_t)lines * P * 8) : user_out;
+  const SideMap omap = fuse_out ? output_side_map(d, pshape, rank) : SideMap();
+  if (fuse_out && d.io_output.enabled && d.io_output.clear_outside) {   // view elements outside the logical domain: zeroed before the store pass
+    Step& z = b.push(ST_ZERO); z.p[0] = user_out; z.i[0] = prodv(d.io_output.shape, rank) * d.batch * 2; z.grid = b.generic_grid(z.i[0]);
+  }
+  if (map0) {
+    const SideMap im = fuse_in ? input_side_map(d, d.shape, rank) : Builder::dense_map(d.shape, rank);
+    const bool store0 = fuse_out && la < 1;
+    const SideMap om = store0 ? omap : Builder::dense_map(pshape, rank);
+    if (!b.emit_lines_r2c(in, store0 ? user_out : out, N, lines, scale, false, 0, &im, &om)) { err = "no mapped r2c line kernel"; return MI355FFT_ERR_UNSUPPORTED; }
+    if (store0) return MI355FFT_OK;
+  } else if (N % 2 == 0) {
     const int rc = b.emit_r2c_even(in, out, N, lines, scale, err);
     if (rc) return rc;
   } else {
@@ -1230,9 +1291,12 @@ int build_r2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     p.grid = b.generic_grid(lines * P);
     b.ir.route += "r2c-full ";
   }
-  if (d.rank > 1) {
-    const int rc = b.emit_nd(out, out, pshape, d.rank, d.batch, false, 1.0f, err, 1);
+  if (rank > 1) {
+    const bool last_mapped = fuse_out && la >= 1;
+    const int rc = last_mapped ? b.emit_nd(out, out, pshape, rank, d.batch, false, 1.0f, err, 1, upper, nullptr, &omap, user_out)
+                               : b.emit_nd(out, out, pshape, rank, d.batch, false, 1.0f, err, 1);
     if (rc) return rc;
+    if (last_mapped) return MI355FFT_OK;
   }
   return finish_side_output(d, b, user_out, out, pshape, false, err);
 }
@@ -1249,22 +1313,49 @@ int build_c2r(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   pshape[0] = P;
   // ioView.input / zeroPad.read live on the packed domain, ioView.output / zeroPad.write on the real one (c2r.js:168-220)
   if (int rv = validate_views(d, err, pshape, d.shape)) return rv;
-  const PtrRef user_out(BUF_OUTPUT, 0);
-  PtrRef in = stage_side_input(d, b, PtrRef(BUF_INPUT, 0), pshape, false, b.ir.in_bytes);
-  PtrRef out = side_output_target(d, b, user_out, d.shape, true, b.ir.out_bytes);
+  const PtrRef user_in(BUF_INPUT, 0), user_out(BUF_OUTPUT, 0);
+  const int rank = d.rank;
+  // ---- sides fused into the launches (as build_r2c): the packed side rides the first inverse c2c axis (rank > 1) or the c2r line
+  // kernel's pre-split loads (rank 1), the real side the c2r line kernel's store pass
+  const bool need_in = d.input.strided || d.io_input.enabled || d.zero_read.enabled;
+  const bool need_out = d.output.strided || d.io_output.enabled || d.zero_write.enabled;
+  const uint32_t upper = rank > 1 ? (((uint32_t)1 << rank) - 1u) & ~1u : 0u;
+  int fa = -1, la = -1;
+  if (rank > 1) Builder::nd_first_last(pshape, rank, upper, fa, la);
+  const bool small = n * 2 < ((int64_t)1 << 31);
+  const bool lines0 = small && b.lines_r2c_kernel(N, true, true) != nullptr;
+  const auto stride_below = [&](int a) { int64_t S = 1; for (int i = 0; i < a; ++i) S *= pshape[i]; return S; };
+  const bool fuse_in = need_in && small && (fa >= 1 ? b.axis_mappable(pshape[fa], stride_below(fa), true) : lines0);
+  const bool fuse_out = need_out && lines0;
+  if (fuse_out && d.io_output.enabled && d.io_output.clear_outside && d.output.strided) { err = "Unsupported: ioView.output.clearOutside with a strided output layout"; return MI355FFT_ERR_UNSUPPORTED; }
+  const bool map0 = fuse_out || (fuse_in && fa < 1);
+  b.ir.out_bytes = side_bytes(d.output, d.io_output, d.shape, rank, d.batch, 4);
+  PtrRef in = user_in;
+  if (fuse_in) b.ir.in_bytes = side_bytes(d.input, d.io_input, pshape, rank, d.batch, 8);
+  else in = stage_side_input(d, b, user_in, pshape, false, b.ir.in_bytes);
+  const SideMap imap = fuse_in ? input_side_map(d, pshape, rank) : SideMap();
+  PtrRef out = user_out;
+  if ((d.output.strided || d.io_output.enabled) && !fuse_out) out = b.alloc_work((uint64_t)n * d.batch * 4);
   PtrRef packed = in;
-  if (d.rank > 1) {
-    // inverse c2c over axes 1.. of the packed spectrum; the caller's input is not modified
+  bool in_mapped_done = false;
+  if (fa >= 1) {
+    // inverse c2c over axes 1.. of the packed spectrum, out of place into the workspace: the caller's input is not modified
     packed = b.alloc_work((uint64_t)lines * P * 8);
-    int64_t ps[MI355FFT_MAX_RANK];
-    for (int i = 0; i < d.rank; ++i) ps[i] = d.shape[i];
-    ps[0] = P;
-    Step& c = b.push(ST_COPY);
-    c.p[0] = in; c.p[1] = packed; c.i[0] = lines * P * 8;
-    int rc = b.emit_nd(packed, packed, ps, d.rank, d.batch, true, 1.0f, err, 1);
+    const bool first_mapped = fuse_in;
+    const int rc = first_mapped ? b.emit_nd(in, packed, pshape, rank, d.batch, true, 1.0f, err, 1, upper, &imap, nullptr)
+                                : b.emit_nd(in, packed, pshape, rank, d.batch, true, 1.0f, err, 1);
     if (rc) return rc;
+    in_mapped_done = first_mapped;
   }
-  if (N % 2 == 0) {
+  if (fuse_out && d.io_output.enabled && d.io_output.clear_outside) {
+    Step& z = b.push(ST_ZERO); z.p[0] = user_out; z.i[0] = prodv(d.io_output.shape, rank) * d.batch; z.grid = b.generic_grid(z.i[0]);
+  }
+  if (map0) {
+    const SideMap im = (fuse_in && !in_mapped_done) ? imap : Builder::dense_map(pshape, rank);
+    const SideMap om = fuse_out ? output_side_map(d, d.shape, rank) : Builder::dense_map(d.shape, rank);
+    if (!b.emit_lines_r2c(packed, out, N, lines, scale, true, 0, &im, &om)) { err = "no mapped c2r line kernel"; return MI355FFT_ERR_UNSUPPORTED; }
+    if (fuse_out) return MI355FFT_OK;
+  } else if (N % 2 == 0) {
     const int rc = b.emit_c2r_even(packed, out, N, lines, scale, err);
     if (rc) return rc;
   } else {
@@ -1453,25 +1544,59 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   }
   const bool embed = d.conv_boundary != MI355FFT_CIRCULAR;
   mi355fft_side_layout dense{};  // strided == 0
+  // ---- sides fused into the launches (fftconv.js:353-373): the zero-padded embed of kernels and data, the
+  // strided lanes and zeroPad.read ride the first forward axis' loads; zeroPad.write, the crop of the linear modes and the output
+  // lanes ride the last inverse axis' store pass — where those axes are line-kernel launches
+  int fa = -1, la = -1;
+  Builder::nd_first_last(fs, rank, 0, fa, la);
+  const auto stride_below = [&](int a) { int64_t S = 1; for (int i = 0; i < a; ++i) S *= fs[i]; return S; };
+  const bool small = fN < ((int64_t)1 << 31);
+  const bool map_fwd = small && fa >= 0 && b.axis_mappable(fs[fa], stride_below(fa), false);
+  const bool map_inv = small && la >= 0 && b.axis_mappable(fs[la], stride_below(la), true);
   // 1. kernels: zero-padded into the FFT domain, transformed once per exec
   PtrRef kf = b.alloc_work((uint64_t)K * fN * 8);
   bool kernel_embed = false;
   for (int i = 0; i < rank; ++i) if (ks[i] != fs[i]) kernel_embed = true;
-  if (kernel_embed) {
-    Step& z = b.push(ST_ZERO); z.p[0] = kf; z.i[0] = K * fN * 2; z.grid = b.generic_grid(K * fN * 2);
-    b.emit_strided(true, kern, kf, dense, ks, rank, K, fs, zero, fN, 0);
+  int rc;
+  if (kernel_embed && map_fwd) {
+    SideMap km = Builder::dense_map(fs, rank);
+    int64_t st = 1;
+    for (int i = 0; i < rank; ++i) { km.stride[i] = st; st *= ks[i]; km.hi[i] = (int)ks[i]; }
+    km.batch_stride = kN;
+    rc = b.emit_nd(kern, kf, fs, rank, K, false, 1.0f, err, 0, 0, &km, nullptr);
   } else {
-    Step& c = b.push(ST_COPY); c.p[0] = kern; c.p[1] = kf; c.i[0] = K * fN * 8;
+    if (kernel_embed) {
+      Step& z = b.push(ST_ZERO); z.p[0] = kf; z.i[0] = K * fN * 2; z.grid = b.generic_grid(K * fN * 2);
+      b.emit_strided(true, kern, kf, dense, ks, rank, K, fs, zero, fN, 0);
+    }
+    rc = b.emit_nd(kernel_embed ? kf : kern, kf, fs, rank, K, false, 1.0f, err);
   }
-  int rc = b.emit_nd(kf, kf, fs, rank, K, false, 1.0f, err);
   if (rc) return rc;
   // 2. data: gather (strided lanes) / embed (linear modes) into the dense FFT domain, forward transform once
   PtrRef xf = b.alloc_work((uint64_t)B * fN * 8);
-  if (embed) { Step& z = b.push(ST_ZERO); z.p[0] = xf; z.i[0] = B * fN * 2; z.grid = b.generic_grid(B * fN * 2); }
-  if (embed || d.input.strided) b.emit_strided(true, in, xf, d.input, d.shape, rank, B, fs, zero, fN, 0);
-  else if (d.zero_read.enabled) { Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = xf; c.i[0] = B * fN * 8; }
-  const bool staged = embed || d.input.strided || d.zero_read.enabled;
-  if (d.zero_read.enabled) { emit_zero_outside(b, xf, d.zero_read, fs, rank, B); b.ir.route += "zero-read "; }
+  const bool side_in = embed || d.input.strided || d.zero_read.enabled;
+  const bool fuse_in = side_in && map_fwd;
+  SideMap xmap;
+  if (fuse_in) {
+    xmap = Builder::dense_map(fs, rank);
+    int64_t st = 1;
+    for (int i = 0; i < rank; ++i) {
+      xmap.stride[i] = d.input.strided ? d.input.strides[i] : st;
+      st *= d.shape[i];
+      int64_t lo = 0, hi = d.shape[i];
+      if (d.zero_read.enabled) { lo = std::max(lo, d.zero_read.start[i]); hi = std::min(hi, d.zero_read.end[i]); }
+      if (hi < lo) hi = lo;
+      xmap.lo[i] = (int)lo; xmap.hi[i] = (int)hi;
+    }
+    xmap.offset = d.input.strided ? d.input.offset_elements : 0;
+    xmap.batch_stride = d.input.strided && d.input.batch_stride_elements > 0 ? d.input.batch_stride_elements : inN;
+  } else {
+    if (embed) { Step& z = b.push(ST_ZERO); z.p[0] = xf; z.i[0] = B * fN * 2; z.grid = b.generic_grid(B * fN * 2); }
+    if (embed || d.input.strided) b.emit_strided(true, in, xf, d.input, d.shape, rank, B, fs, zero, fN, 0);
+    else if (d.zero_read.enabled) { Step& c = b.push(ST_COPY); c.p[0] = in; c.p[1] = xf; c.i[0] = B * fN * 8; }
+    if (d.zero_read.enabled) { emit_zero_outside(b, xf, d.zero_read, fs, rank, B); b.ir.route += "zero-read "; }
+  }
+  const bool staged = side_in && !fuse_in;
   // 1-D, power-of-two FFT length with an LDS-resident line kernel: the product with kernel k's spectrum rides the forward FFT's
   // last stage (kern_lines.hpp fft_lines_mul_kernel), one launch per kernel instead of forward FFT + K pointwise passes
   const LineKernelMeta* mul_m = nullptr;
@@ -1480,7 +1605,8 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     if (mul_m && (mul_m->lds_bytes == 0 || mul_m->R1 <= 1)) mul_m = nullptr;
   }
   if (!mul_m) {
-    rc = b.emit_nd(staged ? xf : in, xf, fs, rank, B, false, 1.0f, err);
+    rc = fuse_in ? b.emit_nd(in, xf, fs, rank, B, false, 1.0f, err, 0, 0, &xmap, nullptr)
+                 : b.emit_nd(staged ? xf : in, xf, fs, rank, B, false, 1.0f, err);
     if (rc) return rc;
   }
   const PtrRef mul_tables = mul_m ? b.line_tables(*mul_m) : PtrRef();
@@ -1488,6 +1614,8 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
   PtrRef y = b.alloc_work((uint64_t)B * fN * 8);
   const float inv_n = (float)(1.0 / (double)fN);
   const bool direct_out = !embed && !d.output.strided;   // the inverse FFT can land in the output itself
+  const bool side_out = embed || d.output.strided || d.zero_write.enabled || d.conv_output_layout != MI355FFT_KERNEL_MAJOR;
+  const bool fuse_out = side_out && map_inv;
   for (int64_t k = 0; k < K; ++k) {
     if (mul_m) {
       Step& st = b.push(ST_LINES);
@@ -1498,12 +1626,31 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       st.i[6] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; st.i[9] = 4;
       st.f[0] = 1.0f;
       st.grid = b.lines_grid(*mul_m, tiles);
-      if (k == 0) b.ir.route += "lines-mul[N=" + std::to_string(fN) + "] ";
+      if (fuse_in) { st.i[10] = 1; st.imap = xmap; st.imap.ax = 0; st.omap = Builder::dense_map(fs, rank); }
+      if (k == 0) b.ir.route += std::string(fuse_in ? "lines-mul-mapped[N=" : "lines-mul[N=") + std::to_string(fN) + "] ";
     } else {
       Step& pm = b.push(ST_POINTWISE);
       pm.p[0] = xf; pm.p[1] = y; pm.p[2] = kf.plus(k * fN * 8);
       pm.i[0] = fN; pm.i[1] = B * fN; pm.i[2] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0; pm.f[0] = 1.0f;
       pm.grid = b.generic_grid(B * fN);
+    }
+    if (fuse_out) {
+      // output element (i - ooff) of the cropped result, lane of kernel k (fftconv.js:868-871), zeroPad.write on the FFT domain
+      SideMap om = Builder::dense_map(fs, rank);
+      int64_t st = 1;
+      for (int i = 0; i < rank; ++i) {
+        om.stride[i] = d.output.strided ? d.output.strides[i] : st;
+        st *= os[i];
+        om.lo[i] = (int)ooff[i]; om.hi[i] = (int)(ooff[i] + os[i]);
+        if (d.zero_write.enabled) { om.zlo[i] = (int)d.zero_write.start[i]; om.zhi[i] = (int)d.zero_write.end[i]; }
+      }
+      if (d.output.strided) { om.offset = d.output.offset_elements + k * kstride; om.batch_stride = d.output.batch_stride_elements > 0 ? d.output.batch_stride_elements : oN; }
+      else if (d.conv_output_layout == MI355FFT_KERNEL_MAJOR) { om.offset = k * B * oN; om.batch_stride = oN; }
+      else { om.offset = k * oN; om.batch_stride = K * oN; }
+      for (int i = 0; i < rank; ++i) om.offset -= ooff[i] * om.stride[i];
+      rc = b.emit_nd(y, y, fs, rank, B, true, inv_n, err, 0, 0, nullptr, &om, out);
+      if (rc) return rc;
+      continue;
     }
     if (direct_out && d.conv_output_layout == MI355FFT_KERNEL_MAJOR) {
       rc = b.emit_nd(y, out.plus(k * B * oN * 8), fs, rank, B, true, inv_n, err);
@@ -1527,7 +1674,7 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       b.emit_strided(false, out, y, ol, os, rank, B, fs, ooff, fN, 0);
     }
   }
-  if (d.zero_write.enabled) b.ir.route += "zero-write ";
+  if (d.zero_write.enabled && !fuse_out) b.ir.route += "zero-write ";
   b.ir.route += "fftconv[K=" + std::to_string(K) + "] ";
   return MI355FFT_OK;
 }
