@@ -471,6 +471,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
 // MAPPED (r02): the real side is read through a.imap (element = one float: strided layout, ioView.input box,
 // zeroPad.read range — zeros outside) and the packed bins leave through a.omap (ioView.output / zeroPad.write / strided layout of
 // the packed domain), as fft_lines_mapped_kernel does for c2c: no gather / embed / zero / extract / scatter launch around the r2c.
+#ifndef MI355_R2C_POST_BATCH
+#define MI355_R2C_POST_BATCH 1
+#endif
 template <class C, bool TRIG = false, bool MAPPED = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
@@ -555,11 +558,29 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
     [[maybe_unused]] long long obase = 0;
     [[maybe_unused]] bool ozero = false, oline = false;
     if constexpr (MAPPED) oline = side_line(a.omap, G0 + t / C::TPL, a.num_lines, obase, ozero);
-    for (int p = MAPPED ? t % C::TPL : t; p < (MAPPED ? PER : live * PER); p += MAPPED ? C::TPL : C::THREADS) {
+    // pairs in batches of QU (the batch's root factors and LDS values requested before the first pair is finished).  Measured
+    // (profiles/r02_split_load_batching.log): no gain for r2c at any size and a loss at N >= 2^14, so QU = 1 here; the c2r twin
+    // below, whose batch covers global loads of the bins themselves, gains 20-40 % with 4
+    constexpr int QU = MI355_R2C_POST_BATCH;
+    const int pend = MAPPED ? PER : live * PER, pstep = MAPPED ? C::TPL : C::THREADS;
+    for (int p0 = MAPPED ? t % C::TPL : t; p0 < pend; p0 += QU * pstep) {
+     cf whs[QU], wls[QU], zks[QU], zms[QU];
+#pragma unroll
+     for (int j = 0; j < QU; ++j) {
+      const int p = p0 + j * pstep;
+      if (p >= pend) break;
+      const int line = MAPPED ? t / C::TPL : p / PER, k = MAPPED ? p : p - line * PER;
+      whs[j] = a.tw_hi[(unsigned)k >> a.fs_shift]; wls[j] = a.tw_lo[(unsigned)k & a.fs_lo_mask];
+      zks[j] = lds[lds_index<C>(line, k)]; zms[j] = lds[lds_index<C>(line, k == 0 ? 0 : H - k)];
+     }
+#pragma unroll
+     for (int j = 0; j < QU; ++j) {
+      const int p = p0 + j * pstep;
+      if (p >= pend) break;
       const int line = MAPPED ? t / C::TPL : p / PER, k = MAPPED ? p : p - line * PER;
       const int km = k == 0 ? 0 : H - k;
-      const cf zk = lds[lds_index<C>(line, k)], zm0 = lds[lds_index<C>(line, km)];
-      const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+      const cf zk = zks[j], zm0 = zms[j];
+      const cf w = cmul(whs[j], wls[j]);
       const cf zmc = {zm0.x, -zm0.y};
       const cf e = (zk + zmc) * 0.5f;
       const cf od = mul_neg_i((zk - zmc) * 0.5f);
@@ -602,6 +623,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
         if (k == 0) x[H] = xm;
         else if (km != k) x[km] = xm;
       }
+     }
     }
     __syncthreads();   // LDS is re-used by the next tile
   }
@@ -692,6 +714,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 //
 // MAPPED (r02): the packed bins are read through a.imap (zeros outside its box) and the real line leaves the
 // LDS line buffer through a.omap (element = one float), as in the r2c kernel above.
+#ifndef MI355_C2R_PRE_BATCH
+#define MI355_C2R_PRE_BATCH 4
+#endif
 template <class C, bool TRIG = false, bool MAPPED = false>
 __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
@@ -727,7 +752,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         if constexpr (MAPPED) iline = side_line(a.imap, G0 + t / C::TPL, a.num_lines, ibase, izero);
         // the pairs are taken in batches of PU: all of a batch's loads (two bins and two root factors per pair) are issued before
         // the first is used — one pair per iteration left the loop waiting out a full memory latency per pair
-        constexpr int PU = 4;
+        constexpr int PU = H >= 8192 ? 1 : MI355_C2R_PRE_BATCH;   // one-line workgroups of 2^14 points and more lose with batches (310 -> 255)
         const int pend = MAPPED ? PER : live * PER, pstep = MAPPED ? C::TPL : C::THREADS;
         for (int p0 = MAPPED ? t % C::TPL : t; p0 < pend; p0 += PU * pstep) {
           cf pks[PU], ms[PU], whs[PU], wls[PU];
