@@ -292,7 +292,10 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_kernel(const LineArgs a)
 
   if constexpr (C::PREFETCH) {
     // (tables first, then the loads: issuing the first tile's loads ahead of the table staging makes every wave of the workgroup
-    // wait at the staging barrier for the slowest wave's data — measured 292 vs 338 GPoints/s at N = 1024 with one-shot grids)
+    // wait at the staging barrier for the slowest wave's data — measured 292 vs 338 GPoints/s at N = 1024 with one-shot grids.
+    // Skipping the LDS table on one-shot grids — each thread's stage-1 roots straight from the global table into registers,
+    // requested behind the tile loads, no staging barrier — measured no better at 1024 (348-362 vs 347-354) and 3-8 % worse at
+    // 64...512: profiles/r02_lines_regtw_ab.log)
     for (int i = t; i < C::TW_LDS_ELEMS; i += C::THREADS) tw_lds[i] = a.tw[i];
     __syncthreads();
     cf v[C::E], vn[C::E];
