@@ -41,11 +41,11 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
 // instances: X(N, lines per workgroup, threads, radices...).  Tile shapes keep every stage's butterfly count (T * N / R) at or
 // above the thread count and two workgroups per CU inside the LDS.
 #define MI355_MIXEDCT_LIST(X)                                                                                                   \
-  X(96, 32, 256, 8, 4, 3) X(192, 16, 256, 8, 8, 3) X(384, 8, 256, 16, 8, 3) X(768, 4, 256, 8, 8, 4, 3) X(1536, 2, 256, 8, 8, 8, 3)       \
-  X(3072, 1, 256, 16, 8, 8, 3) X(160, 16, 256, 8, 4, 5) X(320, 8, 256, 8, 8, 5) X(640, 4, 256, 8, 8, 2, 5) X(1280, 2, 256, 8, 8, 4, 5)  \
-  X(2560, 1, 256, 8, 8, 8, 5) X(1000, 4, 256, 8, 5, 5, 5) X(2000, 2, 256, 16, 5, 5, 5) X(3000, 1, 256, 8, 5, 5, 5, 3)                   \
-  X(105, 32, 256, 7, 5, 3) X(1001, 4, 256, 13, 11, 7) X(360, 8, 256, 8, 5, 3, 3) X(1920, 2, 256, 16, 8, 5, 3) X(2187, 1, 256, 3, 3, 3, 3, 3, 3, 3) \
-  X(500, 8, 256, 4, 5, 5, 5) X(1500, 2, 256, 4, 5, 5, 5, 3) X(120, 32, 256, 8, 5, 3) X(240, 16, 256, 16, 5, 3) X(480, 8, 256, 8, 4, 5, 3) X(720, 4, 256, 16, 5, 3, 3) X(1440, 2, 256, 8, 4, 5, 3, 3)
+  X(96, 32, 256, 8, 4, 3) X(192, 16, 256, 8, 8, 3) X(384, 4, 128, 16, 8, 3) X(768, 4, 256, 8, 8, 4, 3) X(1536, 2, 256, 8, 8, 8, 3)       \
+  X(3072, 2, 512, 16, 8, 8, 3) X(160, 16, 256, 8, 4, 5) X(320, 8, 256, 8, 8, 5) X(640, 4, 256, 8, 8, 2, 5) X(1280, 2, 256, 8, 8, 4, 5)  \
+  X(2560, 1, 256, 8, 8, 8, 5) X(1000, 4, 256, 8, 5, 5, 5) X(2000, 4, 512, 16, 5, 5, 5) X(3000, 2, 512, 8, 5, 5, 5, 3)                   \
+  X(105, 32, 256, 7, 5, 3) X(1001, 8, 512, 13, 11, 7) X(360, 8, 256, 8, 5, 3, 3) X(1920, 4, 512, 16, 8, 5, 3) X(2187, 1, 256, 3, 3, 3, 3, 3, 3, 3) \
+  X(500, 8, 256, 4, 5, 5, 5) X(1500, 2, 256, 4, 5, 5, 5, 3) X(120, 32, 256, 8, 5, 3) X(240, 16, 256, 4, 4, 5, 3) X(480, 8, 256, 8, 4, 5, 3) X(720, 4, 256, 16, 5, 3, 3) X(1440, 2, 256, 8, 4, 5, 3, 3)
 
 struct MixedCtMeta { int id, N, T, threads, lds_bytes; std::vector<int> radices; };
 const std::vector<MixedCtMeta>& mixedct_registry();
