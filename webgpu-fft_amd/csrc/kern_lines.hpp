@@ -106,7 +106,7 @@ struct LineCfg {
   static constexpr int TW_ELEMS = TW1_ELEMS + TW2_ELEMS;
   // the last table of a three-stage plan has about N entries: beyond 32 KB (N = 8192, 16384) it stays in global memory,
   // where its reads are L1/L2 hits, so that the line itself still fits the LDS with room for a second workgroup
-  static constexpr bool TW2_IN_LDS = TW2_ELEMS * 8 <= 32 * 1024;
+  static constexpr bool TW2_IN_LDS = TW2_ELEMS * 8 <= MI355_TW2_LDS_MAX;
   static constexpr int TW_LDS_ELEMS = TW1_ELEMS + (TW2_IN_LDS ? TW2_ELEMS : 0);
   static constexpr int LO_ELEMS = TWID == TWID_FOURSTEP_OUT ? 1024 : 0;
   static constexpr int LDS_BYTES = (DATA_ELEMS + TW_LDS_ELEMS + LO_ELEMS) * 8;

@@ -32,7 +32,7 @@ LineKernelMeta make_meta(int id, int N, int R0, int R1, int R2, int T, bool ic, 
   const int tw2 = nst == 3 ? (R2 - 1) * R0 * R1 : 0;
   m.tw_elems = tw1 + tw2;
   const int lo = twid == 1 ? 1024 : 0;
-  const int tw_lds = tw1 + (tw2 * 8 <= 32 * 1024 ? tw2 : 0);        // LineCfg::TW2_IN_LDS
+  const int tw_lds = tw1 + (tw2 * 8 <= MI355_TW2_LDS_MAX ? tw2 : 0);        // LineCfg::TW2_IN_LDS
   m.lds_bytes = (data + tw_lds + lo) * 8;
   return m;
 }

@@ -99,6 +99,11 @@ struct PtrRef {
 // Line G of the launch (all dims except `ax` in axis-0-fastest order, then the batch) and position idx along `ax`:
 //   reads : inside [lo, hi) on every dim -> phys[offset + sum i_d * stride_d + b * batch_stride], else 0
 //   writes: inside [lo, hi) on every dim -> stored, with the value replaced by 0 outside [zlo, zhi); else not stored
+// a three-stage line kernel keeps its last stage table in LDS up to this many bytes (LineCfg::TW2_IN_LDS, plan.cpp make_meta)
+#ifndef MI355_TW2_LDS_MAX
+#define MI355_TW2_LDS_MAX (32 * 1024)
+#endif
+
 struct SideMap {
   int rank = 0, ax = 0;
   int dims[8] = {1, 1, 1, 1, 1, 1, 1, 1};
