@@ -656,6 +656,54 @@ def test_cfg5_shard_full_size_properties(fft, dev, oracle):
         b.destroy()
 
 
+def test_batches_of_2p24_lines(fft, dev, oracle):
+    """16 Mi lines in one plan: one-shot grids are capped below HIP's 2^32-threads-per-launch limit and the kernels walk the rest
+    (r2c N=64 x 2^24 used to fail with "invalid configuration argument" in its split launch).  Round trip over the whole batch,
+    first / last transforms against the oracle."""
+    n, batch, seed = 64, 1 << 24, 0x5EED0009
+    p = n // 2 + 1
+    x = dev.createBuffer({"size": n * batch * 4})
+    spec = dev.createBuffer({"size": p * batch * 8})
+    back = dev.createBuffer({"size": n * batch * 4})
+    dev.fillRandom(x, 0, n, batch, seed, 0)
+    fwd = fft.createPlan(dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
+    inv = fft.createPlan(dev, {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward"})
+    enc = dev.createCommandEncoder()
+    fwd.exec(enc, {"input": x, "output": spec})
+    inv.exec(enc, {"input": spec, "output": back})
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    e_in = dev.sumsq(x, 0, n * batch)
+    rt = dev.diffSumsq(back, 0, x, 0, 1.0, n * batch)
+    assert np.sqrt(rt / e_in) < 1e-5, f"round trip rel_l2={np.sqrt(rt / e_in):.3e}"
+    for t in (0, batch - 1):
+        xin = fft.downloadF32(dev, x, n, t * n * 4)
+        got = fft.downloadF32(dev, spec, 2 * p, t * p * 8)
+        want = oracle.r2c_ref_packed(xin, n, "none", use_pow2=True)
+        assert oracle.rel_l2(got, want) <= TOL, f"transform {t}"
+    for pl in (fwd, inv):
+        pl.destroy()
+    for b in (x, spec, back):
+        b.destroy()
+    # c2c lines of 8 points, 2^25 of them: the one-shot line grid
+    n, batch = 8, 1 << 25
+    a = dev.createBuffer({"size": n * batch * 8})
+    b2 = dev.createBuffer({"size": n * batch * 8})
+    dev.fillRandom(a, 0, 2 * n, batch, seed + 1, 0)
+    pl = fft.createPlan(dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
+    enc = dev.createCommandEncoder()
+    pl.exec(enc, {"input": a, "output": b2})
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    for t in (0, batch - 1):
+        xin = fft.downloadComplex(dev, a, n, t * n * 8)
+        got = fft.downloadComplex(dev, b2, n, t * n * 8)
+        assert oracle.rel_l2(got, oracle.c2c_ref_batch(xin, [n], 1, "forward")) <= TOL, f"line {t}"
+    pl.destroy()
+    a.destroy()
+    b2.destroy()
+
+
 def test_linearity_at_2p20(fft, dev, oracle):
     n, batch = 1 << 20, 4
     xs = [oracle.random_complex_batch(n, batch, 0x7100 + i).reshape(-1) for i in range(2)]

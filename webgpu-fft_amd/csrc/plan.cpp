@@ -220,13 +220,16 @@ struct Builder {
   }
   // element-wise kernels (grid-stride loops of 256 threads): one element per thread.  Round 1 capped the grid at 16 workgroups per
   // CU; one-shot grids stream 15-20 % faster on this chip (profiles/r02_copy_ceiling.log), so the cap is only an overflow guard.
+  // HIP refuses a launch whose grid x block reaches 2^32 threads: every kernel here walks its items with a grid-stride loop, so
+  // grids are capped well below that for workgroups of up to 1024 threads
+  static constexpr int64_t MAX_BLOCKS = ((int64_t)1 << 22) - 1;
   unsigned generic_grid(int64_t total) const {
     const int64_t blocks = (total + 255) / 256;
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)1 << 30));
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(blocks, MAX_BLOCKS));
   }
   // streaming kernels whose work items are independent chunks: one short-lived workgroup per item.  One-shot grids stream at
   // 6.2-6.5 TB/s on this chip where resident grid-stride loops reach 5.3-5.5 (profiles/r02_copy_ceiling.log)
-  unsigned oneshot_grid(int64_t items) const { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)1 << 30)); }
+  unsigned oneshot_grid(int64_t items) const { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, MAX_BLOCKS)); }
   Step& push(StepKind k) { ir.steps.emplace_back(); ir.steps.back().kind = k; return ir.steps.back(); }
 
   // stage tables of a line kernel: stage 1 [R1-1][R0] roots of order R0*R1, stage 2 [R2-1][R0*R1] of order N
@@ -265,7 +268,7 @@ struct Builder {
     // PASS kernels hoist per-launch state, so they stay resident.  -1 keeps every line kernel resident.
     int tpw = opt.lines_tiles_per_wg;
     if (tpw == 0 && plain_c2c && !m.in_col && !m.out_col && m.twid == 0 && m.N <= 1024) tpw = 1;   // (the r2c / c2r / product variants measured better resident)
-    if (tpw > 0) return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + tpw - 1) / tpw, (int64_t)1 << 30));
+    if (tpw > 0) return (unsigned)std::max<int64_t>(1, std::min<int64_t>((tiles + tpw - 1) / tpw, MAX_BLOCKS));
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, per_cu * opt.compute_units));
   }
 
