@@ -474,6 +474,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
 // MAPPED (r02): the real side is read through a.imap (element = one float: strided layout, ioView.input box,
 // zeroPad.read range — zeros outside) and the packed bins leave through a.omap (ioView.output / zeroPad.write / strided layout of
 // the packed domain), as fft_lines_mapped_kernel does for c2c: no gather / embed / zero / extract / scatter launch around the r2c.
+#ifndef MI355_R2C_POST_VEC
+#define MI355_R2C_POST_VEC 1
+#endif
 #ifndef MI355_R2C_POST_BATCH
 #define MI355_R2C_POST_BATCH 1
 #endif
@@ -561,6 +564,42 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
     [[maybe_unused]] long long obase = 0;
     [[maybe_unused]] bool ozero = false, oline = false;
     if constexpr (MAPPED) oline = side_line(a.omap, G0 + t / C::TPL, a.num_lines, obase, ozero);
+    if constexpr (!TRIG && !MAPPED && MI355_R2C_POST_VEC) {
+      // two adjacent bins per lane: X[k], X[k+1] leave as ONE 16-byte store and so do their mirrors X[H-k-1], X[H-k] (k odd, so that
+      // the last item ends on the self-mirrored bin H/2); bin 0 / H is an item of its own.  Half the loop trips and store
+      // instructions of the pair-per-lane form below (which the DCT and mapped variants keep).
+      typedef float f4w __attribute__((ext_vector_type(4), aligned(8)));
+      constexpr int QP = H / 4, PERV = QP + 1;
+      const auto split = [&](cf zk, cf zm0, int k, cf& xk, cf& xm) {
+        const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+        const cf zmc = {zm0.x, -zm0.y};
+        const cf e = (zk + zmc) * 0.5f;
+        const cf od = mul_neg_i((zk - zmc) * 0.5f);
+        const cf wo = cmul(w, od);
+        xk = (e + wo) * a.scale;
+        xm = (e - wo) * a.scale;
+        xm.y = -xm.y;
+      };
+      for (int p = t; p < live * PERV; p += C::THREADS) {
+        const int line = p / PERV, j = p - line * PERV;
+        cf* x = a.out + (G0 + line) * a.out_outer_stride;
+        if (j == QP) {
+          const cf z0 = lds[lds_index<C>(line, 0)];
+          x[0] = cf{(z0.x + z0.y) * a.scale, 0.0f};
+          x[H] = cf{(z0.x - z0.y) * a.scale, 0.0f};
+          continue;
+        }
+        const int k = 2 * j + 1;
+        cf xk0, xm0, xk1, xm1;
+        split(lds[lds_index<C>(line, k)], lds[lds_index<C>(line, H - k)], k, xk0, xm0);
+        split(lds[lds_index<C>(line, k + 1)], lds[lds_index<C>(line, H - k - 1)], k + 1, xk1, xm1);
+        *reinterpret_cast<f4w*>(x + k) = f4w{xk0.x, xk0.y, xk1.x, xk1.y};
+        if (k + 1 == H / 2) x[H - k] = xm0;                                   // X[H/2] is its own mirror: already stored
+        else *reinterpret_cast<f4w*>(x + (H - k - 1)) = f4w{xm1.x, xm1.y, xm0.x, xm0.y};
+      }
+      __syncthreads();   // LDS is re-used by the next tile
+      continue;
+    }
     // pairs in batches of QU (the batch's root factors and LDS values requested before the first pair is finished).  Measured
     // (profiles/r02_split_load_batching.log): no gain for r2c at any size and a loss at N >= 2^14, so QU = 1 here; the c2r twin
     // below, whose batch covers global loads of the bins themselves, gains 20-40 % with 4
@@ -717,6 +756,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 //
 // MAPPED (r02): the packed bins are read through a.imap (zeros outside its box) and the real line leaves the
 // LDS line buffer through a.omap (element = one float), as in the r2c kernel above.
+#ifndef MI355_C2R_PRE_VEC
+#define MI355_C2R_PRE_VEC 1
+#endif
 #ifndef MI355_C2R_PRE_BATCH
 #define MI355_C2R_PRE_BATCH 4
 #endif
@@ -753,6 +795,58 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         [[maybe_unused]] long long ibase = 0;
         [[maybe_unused]] bool izero = false, iline = false;
         if constexpr (MAPPED) iline = side_line(a.imap, G0 + t / C::TPL, a.num_lines, ibase, izero);
+        if constexpr (!TRIG && !MAPPED && MI355_C2R_PRE_VEC && H >= 2048) {
+          // (N >= 4096: below that the pair-per-lane batches further down measured 5-10 % faster, profiles/r02_split_vec_ab.log)
+          // two adjacent bins per lane: X[k], X[k+1] and their mirrors X[H-k-1], X[H-k] arrive as two 16-byte loads (k odd; the last
+          // item ends on the self-mirrored bin H/2; bins 0 / H are an item of their own), PV items' loads in flight at a time
+          typedef float f4w __attribute__((ext_vector_type(4), aligned(8)));
+          constexpr int QP = H / 4, PERV = QP + 1, PV = H >= 8192 ? 1 : 2;
+          const auto presplit = [&](cf pk, cf m, int k, cf wh, cf wl, cf* xl) {
+            if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
+            const cf w = cmul(wh, wl);
+            const cf mc = {m.x, -m.y};
+            const cf e = pk + mc;
+            const cf o = cmul_conj(pk - mc, w);
+            xl[k] = e + mul_pos_i(o);
+            if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
+          };
+          const int vend = live * PERV;
+          for (int p0 = t; p0 < vend; p0 += PV * C::THREADS) {
+            f4w up[PV], dn[PV];
+            cf wh[PV][2], wl[PV][2];
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+              const int p = p0 + i * C::THREADS;
+              if (p >= vend) break;
+              const int l = p / PERV, j = p - l * PERV;
+              const cf* x = a.in + (G0 + l) * a.in_outer_stride;
+              if (j == QP) {
+                const cf x0 = x[0], xh = x[H];
+                up[i] = f4w{x0.x, x0.y, xh.x, xh.y};
+                wh[i][0] = a.tw_hi[0]; wl[i][0] = a.tw_lo[0];
+              } else {
+                const int k = 2 * j + 1;
+                up[i] = *reinterpret_cast<const f4w*>(x + k);
+                dn[i] = *reinterpret_cast<const f4w*>(x + (H - k - 1));
+#pragma unroll
+                for (int c = 0; c < 2; ++c) { wh[i][c] = a.tw_hi[(unsigned)(k + c) >> a.fs_shift]; wl[i][c] = a.tw_lo[(unsigned)(k + c) & a.fs_lo_mask]; }
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+              const int p = p0 + i * C::THREADS;
+              if (p >= vend) break;
+              const int l = p / PERV, j = p - l * PERV;
+              cf* xl = lds + l * C::PITCH;
+              if (j == QP) presplit(cf{up[i].x, up[i].y}, cf{up[i].z, up[i].w}, 0, wh[i][0], wl[i][0], xl);
+              else {
+                const int k = 2 * j + 1;
+                presplit(cf{up[i].x, up[i].y}, cf{dn[i].z, dn[i].w}, k, wh[i][0], wl[i][0], xl);          // X[k], X[H-k]
+                presplit(cf{up[i].z, up[i].w}, cf{dn[i].x, dn[i].y}, k + 1, wh[i][1], wl[i][1], xl);      // X[k+1], X[H-k-1]
+              }
+            }
+          }
+        } else {
         // the pairs are taken in batches of PU: all of a batch's loads (two bins and two root factors per pair) are issued before
         // the first is used — one pair per iteration left the loop waiting out a full memory latency per pair
         constexpr int PU = H >= 8192 ? 1 : MI355_C2R_PRE_BATCH;   // one-line workgroups of 2^14 points and more lose with batches (310 -> 255)
@@ -806,6 +900,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
             xl[k] = e + mul_pos_i(o);
             if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
           }
+        }
         }
         __syncthreads();
         const cf* zl = lds + lclamp * C::PITCH;
