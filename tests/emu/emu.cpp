@@ -118,11 +118,13 @@ int emu_check_registry(char* msg, size_t msg_bytes) {
     ++cur;                                                                                                   \
   }
 #define LINE_ROW(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, false, false, false, false, 0) CHECK(N, R0, R1, R2, T, false, false, true, true, 0)
+#define LINE_ROW_TRIG(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, false, false, false, false, 4)
 #define LINE_PASS_A(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, true, true, false, false, 0) CHECK(N, R0, R1, R2, T, true, true, true, false, 0) CHECK(N, R0, R1, R2, T, true, true, true, true, 0)
 #define LINE_PASS_B(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, false, true, false, false, 2) CHECK(N, R0, R1, R2, T, false, true, false, true, 2)
 #define LINE_COL_RAGGED(N, R0, R1, R2, T) CHECK(N, R0, R1, R2, T, true, true, false, false, 3) CHECK(N, R0, R1, R2, T, true, true, true, true, 3)
 #include "line_kernels.def"
 #undef LINE_ROW
+#undef LINE_ROW_TRIG
 #undef LINE_PASS_A
 #undef LINE_PASS_B
 #undef LINE_COL_RAGGED
@@ -156,6 +158,7 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   if (const char* e = std::getenv("MI355_EMU_LINES_C2R")) opt.lines_c2r = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_TRIG_REAL")) opt.trig_real = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_TRIG_FUSED")) opt.trig_fused = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_TRIG_ALT")) opt.trig_alt = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_CONV_LINES")) opt.conv_lines = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_CONV_FUSED_MAX_POINTS")) opt.conv_fused_max_points = std::atoll(e);
   emu::g_xcds = std::getenv("MI355_EMU_XCDS") ? (unsigned)std::atoi(std::getenv("MI355_EMU_XCDS")) : 2u;

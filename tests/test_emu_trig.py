@@ -31,7 +31,8 @@ def test_trig_1d(oracle, typ, n):
 
 @pytest.mark.parametrize("typ", TYPES)
 @pytest.mark.parametrize("n,fused,backend", [(4, "1", "r2c-split"), (100, "1", "r2c-split"), (256, "1", "lines-r2c"), (4096, "1", "lines-r2c"),
-                                             (4096, "2", "xcd-r2c"), (256, "1", "lines-dct2"), (4096, "1", "lines-dct2"), (8192, "1", "lines-dct2")])
+                                             (4096, "2", "xcd-r2c"), (256, "1", "lines-dct2"), (2048, "1", "lines-dct2"), (2048, "1", "lines-dct2-plain-shape"),
+                                             (4096, "1", "lines-dct2"), (8192, "1", "lines-dct2")])
 def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
     """dense axis 0 (kern_trig.hpp kinds 8..15): dct2/dst2/dct3/dst3 as Makhoul permutation + a real FFT of length N over each
     r2c / c2r back-end, dct4/dst4 as a complex FFT of N/2, dct1/dst1 as the r2c of the real extension; the general 2N route
@@ -40,7 +41,9 @@ def test_trig_real_fft_route(oracle, monkeypatch, typ, n, fused, backend):
     # backend "lines-dct2": the DCT-II / DST-II computation (dct2 / dst2 forward, dct3 / dst3 inverse) as ONE line-kernel launch —
     # permutation in the LDS staging, real FFT, phase in the split (kern_lines.hpp fft_lines_r2c_kernel<C, TRIG>) — and the
     # DCT-III / DST-III computation the same way on the c2r line kernel; the other back-ends run with that fusion off
-    one_launch = backend == "lines-dct2"
+    # N = 2048 runs on the alternate ROW shape kept for these launches (line_kernels.def LINE_ROW_TRIG); "-plain-shape" turns that off
+    one_launch = backend.startswith("lines-dct2")
+    monkeypatch.setenv("MI355_EMU_TRIG_ALT", "0" if backend.endswith("plain-shape") else "1")
     monkeypatch.setenv("MI355_EMU_TRIG_FUSED", "1" if one_launch else "0")
     if one_launch and typ[3] in "14":
         pytest.skip("DCT-II / DST-II computations only")

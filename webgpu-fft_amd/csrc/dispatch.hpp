@@ -32,6 +32,14 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
   if (id == cur) {                                                                       \
     if constexpr ((FAM) == FAMILY) {                                                     \
       using C = LineCfg<N, R0, R1, R2, T, IC, OC, SI, SO, TW>;                           \
+      if constexpr ((TW) == 4) {   /* ROW_ALT_TRIG: only the one-launch DCT / DST kernels exist for these shapes */ \
+        if constexpr (!(SI)) {                                                           \
+          if (a.real_mode == 5 || a.real_mode == 6) { l.launch(fft_lines_r2c_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); return true; } \
+        } else {                                                                         \
+          if (a.real_mode == 7 || a.real_mode == 8) { l.launch(fft_lines_c2r_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); return true; } \
+        }                                                                                \
+        return false;                                                                    \
+      } else {                                                                           \
       if constexpr (!(IC) && !(OC) && !(SI) && !(SO) && (TW) == 0 && C::NSTAGES >= 2) {   \
         if (a.real_mode == 1) {                                                          \
           if (a.mapped) l.launch(fft_lines_r2c_kernel<C, false, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
@@ -74,12 +82,15 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
       if (a.mapped) return false;                                                        \
       l.launch(fft_lines_kernel<C>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a); \
       return true;                                                                       \
+      }                                                                                  \
     } else return false;                                                                 \
   }                                                                                      \
   ++cur;
 #define LINE_ROW(N, R0, R1, R2, T)                                          \
   MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, false, false, 0) \
   MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, true, true, 0)
+#define LINE_ROW_TRIG(N, R0, R1, R2, T) \
+  MI_LINE_CASE(row_family(N), N, R0, R1, R2, T, false, false, false, false, 4)
 #define LINE_PASS_A(N, R0, R1, R2, T)                               \
   MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, false, false, 0) \
   MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, false, 0)  \
@@ -92,6 +103,7 @@ bool launch_lines_family(int id, const LineArgs& a, unsigned grid, L& l) {
   MI_LINE_CASE(FAM_PASS_A, N, R0, R1, R2, T, true, true, true, true, 3)
 #include "line_kernels.def"
 #undef LINE_ROW
+#undef LINE_ROW_TRIG
 #undef LINE_PASS_A
 #undef LINE_PASS_B
 #undef LINE_COL_RAGGED

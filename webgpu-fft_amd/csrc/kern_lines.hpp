@@ -57,7 +57,10 @@ template <bool NT = false> MI_DEV void st_stream(cf* p, cf v) {
 enum : int { TWID_NONE = 0, TWID_FOURSTEP_OUT = 1, TWID_FOURSTEP_IN = 2,
              // no roots; COL sides whose group width S is NOT a multiple of T (e.g. the 513 packed bins of a 2-D r2c): tiles are
              // numbered per group (fs_group = tiles per group), the last tile of a group is ragged
-             COL_RAGGED = 3 };
+             COL_RAGGED = 3,
+             // registry tag only: an alternate shape of a plain ROW configuration, picked by the one-launch DCT / DST routes
+             // (more, smaller workgroups per CU; the kernels see TWID_NONE)
+             ROW_ALT_TRIG = 4 };
 
 struct LineArgs {
   const cf* in;
@@ -84,7 +87,7 @@ template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_
 struct LineCfg {
   static constexpr int N = N_, R0 = R0_, R1 = R1_, R2 = R2_, T = T_;
   static constexpr bool IN_COL = IN_COL_, OUT_COL = OUT_COL_, SWAP_IN = SWAP_IN_, SWAP_OUT = SWAP_OUT_;
-  static constexpr int TWID = TWID_;
+  static constexpr int TWID = TWID_ == ROW_ALT_TRIG ? (int)TWID_NONE : TWID_;
   static_assert(R0 * R1 * R2 == N, "radix product");
   static constexpr int NSTAGES = (R1 == 1) ? 1 : (R2 == 1 ? 2 : 3);
   static_assert(R1 > 1 || R2 == 1, "R2 needs R1");
@@ -106,7 +109,8 @@ struct LineCfg {
   static constexpr int TW_ELEMS = TW1_ELEMS + TW2_ELEMS;
   // the last table of a three-stage plan has about N entries: beyond 32 KB (N = 8192, 16384) it stays in global memory,
   // where its reads are L1/L2 hits, so that the line itself still fits the LDS with room for a second workgroup
-  static constexpr bool TW2_IN_LDS = TW2_ELEMS * 8 <= MI355_TW2_LDS_MAX;
+  // (the alternate DCT shapes trade the table's LDS residence for workgroups per CU already above 8 KB)
+  static constexpr bool TW2_IN_LDS = TW2_ELEMS * 8 <= (TWID_ == ROW_ALT_TRIG ? 8 * 1024 : MI355_TW2_LDS_MAX);
   static constexpr int TW_LDS_ELEMS = TW1_ELEMS + (TW2_IN_LDS ? TW2_ELEMS : 0);
   static constexpr int LO_ELEMS = TWID == TWID_FOURSTEP_OUT ? 1024 : 0;
   static constexpr int LDS_BYTES = (DATA_ELEMS + TW_LDS_ELEMS + LO_ELEMS) * 8;

@@ -32,7 +32,7 @@ LineKernelMeta make_meta(int id, int N, int R0, int R1, int R2, int T, bool ic, 
   const int tw2 = nst == 3 ? (R2 - 1) * R0 * R1 : 0;
   m.tw_elems = tw1 + tw2;
   const int lo = twid == 1 ? 1024 : 0;
-  const int tw_lds = tw1 + (tw2 * 8 <= MI355_TW2_LDS_MAX ? tw2 : 0);        // LineCfg::TW2_IN_LDS
+  const int tw_lds = tw1 + (tw2 * 8 <= (twid == 4 ? 8 * 1024 : MI355_TW2_LDS_MAX) ? tw2 : 0);        // LineCfg::TW2_IN_LDS
   m.lds_bytes = (data + tw_lds + lo) * 8;
   return m;
 }
@@ -45,6 +45,8 @@ const std::vector<LineKernelMeta>& line_kernel_registry() {
 #define LINE_ROW(N, R0, R1, R2, T)                                             \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, false, false, 0)); \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, true, true, 0));
+#define LINE_ROW_TRIG(N, R0, R1, R2, T)                                        \
+  r.push_back(make_meta(id++, N, R0, R1, R2, T, false, false, false, false, 4));
 #define LINE_PASS_A(N, R0, R1, R2, T)                                        \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, false, false, 0)); \
   r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, false, 0));  \
@@ -57,6 +59,7 @@ const std::vector<LineKernelMeta>& line_kernel_registry() {
   r.push_back(make_meta(id++, N, R0, R1, R2, T, true, true, true, true, 3));
 #include "line_kernels.def"
 #undef LINE_ROW
+#undef LINE_ROW_TRIG
 #undef LINE_PASS_A
 #undef LINE_PASS_B
 #undef LINE_COL_RAGGED
@@ -139,6 +142,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_FUSE_VIEWS")) o.fuse_views = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= -1) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_TRIG_ALT")) o.trig_alt = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPIN_LIMIT")) { const long long v = std::atoll(s); if (v >= 1 && v <= 0x7fffffffll) o.xcd_spin_limit = (unsigned)v; }
   if (const char* s = std::getenv("MI355FFT_XCD_RES_DEPTH")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_res_depth = v; }
@@ -388,6 +392,8 @@ struct Builder {
     const int64_t H = N / 2;
     const LineKernelMeta* m = lines_r2c_kernel(N, c2r, im != nullptr);
     if (!m) return false;
+    // DCT-II / DST-II launches: the alternate shapes (DCT-III / DST-III on the c2r kernel measured -9...+5 % with them and keep the plain ones)
+    if (trig && !c2r && opt.trig_alt) { if (const LineKernelMeta* alt = find_line_kernel((int)H, false, false, false, false, 4)) m = alt; }
     std::vector<float2h> lo(1024), hi((size_t)std::max<int64_t>(1, (H + 1023) >> 10));
     for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << 10, N);
