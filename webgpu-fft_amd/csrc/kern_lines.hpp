@@ -83,6 +83,9 @@ struct LineArgs {
   SideMap imap, omap;
 };
 
+#ifndef MI355_NT_MAX_N
+#define MI355_NT_MAX_N 16384
+#endif
 template <int N_, int R0_, int R1_, int R2_, int T_, bool IN_COL_, bool OUT_COL_, bool SWAP_IN_, bool SWAP_OUT_, int TWID_>
 struct LineCfg {
   static constexpr int N = N_, R0 = R0_, R1 = R1_, R2 = R2_, T = T_;
@@ -122,7 +125,7 @@ struct LineCfg {
   // plain ROW transforms of 256 points and more stream every byte once: nontemporal loads / stores measured +4...+6 % on the
   // one-shot and on the resident grids (N = 64: -10 %; profiles/r02_lines_nt_ab.log).  The XCD kernels pick their own policy per
   // call site (their intermediate must stay cached), the fused r2c / c2r / product variants keep the default.
-  static constexpr bool STREAM_NT = !IN_COL && !OUT_COL && TWID == TWID_NONE && N >= 256;
+  static constexpr bool STREAM_NT = !IN_COL && !OUT_COL && TWID == TWID_NONE && N >= 256 && N <= MI355_NT_MAX_N;
   static constexpr bool PREFETCH = MI355_LINES_PREFETCH && !IN_COL && !OUT_COL && TWID == TWID_NONE && NSTAGES == 2 && N >= 64 && N <= 2048;
   static_assert(THREADS <= 1024, "workgroup too large");
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
