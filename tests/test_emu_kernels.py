@@ -423,6 +423,7 @@ def test_real_four_step_solo_sizes(oracle, monkeypatch, lg, label):
     """real / Hermitian four-step with one workgroup per transform (real lines of at most 512 KB): r2c against the oracle, c2r back"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")       # 2^15 would otherwise be a single line kernel launch
+    monkeypatch.setenv("MI355_EMU_LINES_C2R", "3")       # ... on the c2r side too since r02 (3: line kernel up to N = 2^14 only)
     monkeypatch.setenv("MI355_EMU_CUS", "3")
     monkeypatch.setenv("MI355_EMU_MAX_GRID", "3")
     n, batch = 1 << lg, 7

@@ -456,6 +456,7 @@ def test_c2r_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     against the oracle's c2r of the oracle's own spectrum, and the round trip back to the signal"""
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     monkeypatch.setenv("MI355FFT_LINES_R2C", "0")
+    monkeypatch.setenv("MI355FFT_LINES_C2R", "3")    # 2^15 is a line-kernel launch by default since r02: keep the four-step under test
     n = 1 << lg
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 0xE200 + lg).reshape(-1)

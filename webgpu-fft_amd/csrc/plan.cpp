@@ -381,7 +381,9 @@ struct Builder {
   const LineKernelMeta* lines_r2c_kernel(int64_t N, bool c2r, bool mapped) const {
     const int64_t H = N / 2;
     if (opt.force_generic || !(c2r ? opt.lines_c2r : opt.lines_r2c) || (N & 1) || !is_pow2(H) || H < (c2r ? 2 : 64) || H > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return nullptr;
-    if (c2r && H > 8192 && opt.lines_c2r != 2 && !mapped) return nullptr;     // N = 2^15: the Hermitian four-step in solo mode measured faster (322 vs 304)   // xcd_fused == 2: emulation tests of the fused instances
+    // (N = 2^15 c2r: round 1 kept the Hermitian four-step in solo mode there, 322 vs 304; with the 16-byte pre-split accesses of r02
+    // the line kernel is ahead, 347 vs 320; lines_c2r = 3 restores the old choice)   // xcd_fused == 2: emulation tests of the fused instances
+    if (c2r && H > 8192 && opt.lines_c2r == 3 && !mapped) return nullptr;
     const LineKernelMeta* m = find_line_kernel((int)H, false, false, c2r, c2r, 0);
     if (!m || (!c2r && m->lds_bytes == 0)) return nullptr;
     if (mapped && (!opt.fuse_views || m->lds_bytes == 0 || m->R1 <= 1)) return nullptr;   // the mapped forms keep the line in LDS

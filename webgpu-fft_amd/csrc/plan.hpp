@@ -165,7 +165,7 @@ struct PlannerOptions {
   int conv_lines = 1;                  // fftconv: kernel-spectrum product fused behind the forward line FFT (1-D, power-of-two FFT length <= max_line)
   int trig_fused = 1;                  // dct2 / dst2 of dense lines (half length a line-kernel size): permutation + real FFT + phase in one launch
   int trig_real = 1;                   // dct2/dst2/dct3/dst3 along a dense even axis through a real FFT of length N (kern_trig.hpp)
-  int lines_c2r = 1;                   // c2r twin (pair pre-split from global into LDS before the first stage): half lengths <= 8192
+  int lines_c2r = 1;                   // c2r twin (pre-split from global into LDS before the first stage): half lengths <= 16384 (3: <= 8192, the round-1 choice)
                                        // (N = 256: 528 vs 133 G real points/s, 1024: 471 vs 243, 2^14: 312 vs 270); 2 forces it at 2^15 too
   int lines_r2c = 1;                   // r2c with a half length of 64..max_line: split fused into the line kernel
   int max_line = 16384;                // longest power-of-two line given to a single workgroup (4096: N = 8192, 16384 take the four-step routes)
