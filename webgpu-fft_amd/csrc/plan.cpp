@@ -233,6 +233,15 @@ struct Builder {
   }
   // streaming kernels whose work items are independent chunks: one short-lived workgroup per item.  One-shot grids stream at
   // 6.2-6.5 TB/s on this chip where resident grid-stride loops reach 5.3-5.5 (profiles/r02_copy_ceiling.log)
+  // work items of r2c_post_kernel / c2r_pre_kernel (kern_generic.hpp): 512 bin pairs each; lines of at most 256 pairs sit side by side
+  static int64_t split_items(int64_t lines, int64_t H) {
+    const int64_t pairs = H / 4 + 1;
+    if (pairs > 256) return lines * ((pairs + 511) / 512);
+    int sh = 0;
+    while (((int64_t)1 << sh) < pairs) ++sh;
+    const int64_t per_item = 2 * (256 >> sh);
+    return (lines + per_item - 1) / per_item;
+  }
   unsigned oneshot_grid(int64_t items) const { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, MAX_BLOCKS)); }
   Step& push(StepKind k) { ir.steps.emplace_back(); ir.steps.back().kind = k; return ir.steps.back(); }
 
@@ -432,7 +441,7 @@ struct Builder {
     st.p[0] = z; st.p[1] = out;
     split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P; st.f[0] = scale;
-    st.grid = oneshot_grid(lines * ((H / 4 + 1 + 511) / 512));      // items of 512 bin pairs (r2c_post_kernel)
+    st.grid = oneshot_grid(split_items(lines, H));      // items of 512 bin pairs (r2c_post_kernel)
     ir.route += "r2c-split ";
     return MI355FFT_OK;
   }
@@ -446,7 +455,7 @@ struct Builder {
     st.p[0] = packed; st.p[1] = z;
     split_roots(st, N, H / 2 + 1);
     st.i[0] = H; st.i[1] = lines; st.i[2] = P;
-    st.grid = oneshot_grid(lines * ((H / 4 + 1 + 511) / 512));      // items of 512 bin pairs (c2r_pre_kernel)
+    st.grid = oneshot_grid(split_items(lines, H));      // items of 512 bin pairs (c2r_pre_kernel)
     // unnormalised inverse of length H lands x[2n] + i x[2n+1]: exactly the real output, read as complex
     int rc = emit_axis(z, out, H, 1, lines, true, scale, err);
     if (rc) return rc;
