@@ -360,3 +360,40 @@ def test_c2r_ioview_zeropad(oracle, monkeypatch, shape, io_view, zero_pad, fuse)
     want = _extract(y, shape, vout, batch, 1, sentinel)
     scale = max(1.0, float(np.max(np.abs(want))))
     assert got.shape == want.shape and float(np.max(np.abs(got.astype(np.float64) - want))) <= 3e-5 * scale, route
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_r2c_c2r_strided_sides(oracle, monkeypatch, fuse):
+    """strided physical layouts on the real transforms: non-unit element strides on the real side (4-byte accesses in the mapped
+    kernels, no pair fast path) and on the packed side, odd offsets, padded batch pitches; elements no logical index maps to stay
+    untouched.  fuse=1: one mapped launch each way; fuse=0: gather / scatter passes"""
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fuse))
+    n, batch = 256, 3
+    p = n // 2 + 1
+    li = {"strides": [3], "offset": 5, "batch_stride": 3 * n + 11}
+    lo = {"strides": [2], "offset": 1, "batch_stride": 2 * p + 7}
+    x = oracle.random_real_batch(n, batch, 0xABCD).reshape(batch, n)
+    phys_in = np.full(li["offset"] + (batch - 1) * li["batch_stride"] + (n - 1) * 3 + 1, 9.0, np.float32)
+    for b in range(batch):
+        phys_in[li["offset"] + b * li["batch_stride"] + 3 * np.arange(n)] = x[b]
+    out_elems = lo["offset"] + (batch - 1) * lo["batch_stride"] + (p - 1) * 2 + 1
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_elems)
+    desc = _abi.make_desc("r2c", [n], batch, "forward", "none", input_layout=li, output_layout=lo)
+    got, route, launches = emu.run_plan(desc, phys_in, sentinel.size, out_init=sentinel)
+    assert (route.split() == ["lines-r2c-mapped[N=256]"] and launches == 1) if fuse else ("gather" in route and "scatter" in route), route
+    want = sentinel.copy().reshape(-1, 2)
+    for b in range(batch):
+        want[lo["offset"] + b * lo["batch_stride"] + 2 * np.arange(p)] = oracle.r2c_ref_packed(x[b], n, "none").reshape(-1, 2)
+    assert float(np.max(np.abs(got.astype(np.float64) - want.reshape(-1)))) <= 2e-5 * float(np.max(np.abs(want))), route
+    # c2r back: packed side strided by 2, real side strided by 3
+    ri = lo
+    ro = {"strides": [3], "offset": 2, "batch_stride": 3 * n + 5}
+    real_elems = ro["offset"] + (batch - 1) * ro["batch_stride"] + (n - 1) * 3 + 1
+    rs = np.full(real_elems, -3.0, np.float32)
+    desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward", input_layout=ri, output_layout=ro)
+    back, route, launches = emu.run_plan(desc, got, rs.size, out_init=rs)
+    assert (route.split() == ["lines-c2r-mapped[N=256]"] and launches == 1) if fuse else ("gather" in route and "scatter" in route), route
+    wantr = rs.copy()
+    for b in range(batch):
+        wantr[ro["offset"] + b * ro["batch_stride"] + 3 * np.arange(n)] = x[b]
+    assert float(np.max(np.abs(back - wantr))) < 3e-6, route
