@@ -52,6 +52,31 @@ def test_c2c_two_pass(oracle, monkeypatch, lg, direction):
     check(got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"two-pass 2^{lg} {direction}")
 
 
+def test_c2c_line32k(oracle, monkeypatch):
+    """N = 2^15 in one workgroup (kern_line32k.hpp): the line in the registers of 512 threads, both Stockham exchanges through LDS
+    in two halves; more lines than (emulated) workgroups; MI355_EMU_LINE32K=0 is the four-step route it replaces"""
+    n, batch = 1 << 15, 5
+    x = oracle.random_complex_batch(n, batch, 0xB320).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward"), ("forward", "unitary")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.split() == ["line32k[N=32768]"] and launches == 1, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"line32k {direction} {norm}")
+    monkeypatch.setenv("MI355FFT_LINE32K", "0")          # (plan_only reads the product planner's environment)
+    assert emu.plan_only(_abi.make_desc("c2c", [n], batch, "forward", "none"))[0].startswith("xcd-solo[N=128x256]")
+    monkeypatch.delenv("MI355FFT_LINE32K")
+    # the real transforms of 2^16 points ride it through the half-length route
+    m = 1 << 16
+    xr = oracle.random_real_batch(m, 2, 0xB321).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(xr[b * m:(b + 1) * m], m, "none") for b in range(2)])
+    got, route, _ = emu.run_plan(_abi.make_desc("r2c", [m], 2, "forward", "none"), xr, want.size)
+    assert route.split() == ["line32k[N=32768]", "r2c-split"], route
+    check(got, want, "r2c 2^16 over line32k", 1e-5)
+    back, route, _ = emu.run_plan(_abi.make_desc("c2r", [m], 2, "inverse", "backward"), want, m * 2)
+    assert "line32k[N=32768]" in route and "c2r-split" in route, route
+    check(back, xr, "c2r 2^16 over line32k", 1e-5)
+
+
 @pytest.mark.parametrize("lg,grid", [(13, 4), (14, 8), (15, 8)])
 def test_c2c_two_pass_hoisted_fourstep_roots(oracle, lg, grid, monkeypatch):
     """grid*T a multiple of N1: pass B computes its four-step roots once per launch (loop-invariant registers)"""
@@ -424,6 +449,7 @@ def test_real_four_step_solo_sizes(oracle, monkeypatch, lg, label):
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")       # 2^15 would otherwise be a single line kernel launch
     monkeypatch.setenv("MI355_EMU_LINES_C2R", "3")       # ... on the c2r side too since r02 (3: line kernel up to N = 2^14 only)
+    monkeypatch.setenv("MI355_EMU_LINE32K", "0")         # 2^16 real would otherwise take the half-length route over the 2^15 line kernel
     monkeypatch.setenv("MI355_EMU_CUS", "3")
     monkeypatch.setenv("MI355_EMU_MAX_GRID", "3")
     n, batch = 1 << lg, 7
@@ -541,6 +567,7 @@ def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
     """transforms of at most 1 MiB: one workgroup walks a whole transform (both passes, its own workspace slot, no cross-
     workgroup synchronisation); more transforms than workgroups so that every slot is re-used"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_LINE32K", "0")              # 2^15 is a single-workgroup line by default (kern_line32k.hpp)
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_MAX_GRID", str(cus))        # fewer workgroups than transforms
     n, batch = 1 << lg, 7

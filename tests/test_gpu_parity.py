@@ -134,6 +134,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
         pytest.skip("no fused instance")
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
+    monkeypatch.setenv("MI355FFT_LINE32K", "0")           # ... and so would 2^15 (kern_line32k.hpp, test_c2c_line32k)
     n, batch = 1 << lg, 3 if lg <= 18 else 2
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
@@ -202,9 +203,34 @@ def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction} {norm}")
 
 
+@pytest.mark.parametrize("batch", [1, 5, 700])
+def test_c2c_line32k(fft, dev, oracle, batch):
+    """N = 2^15 in one workgroup (kern_line32k.hpp: the line in registers, both exchanges through LDS in halves): one launch, both
+    directions, every normalisation, more lines than workgroups; and the real transforms of 2^16 points that ride it"""
+    n = 1 << 15
+    x = oracle.random_complex_batch(n, batch, 0xC800 + batch).reshape(-1)
+    for direction in ("forward", "inverse"):
+        for norm in (("none", "backward", "unitary") if batch == 5 else ("backward",)):
+            got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+            assert route.split() == ["line32k[N=32768]"] and launches == 1, route
+            check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"line32k x{batch} {direction} {norm}")
+    if batch == 5:
+        m = 1 << 16
+        xr = oracle.random_real_batch(m, batch, 0xC900).reshape(-1)
+        p = m // 2 + 1
+        spec, (route, _) = run_plan(fft, dev, {"type": "r2c", "shape": [m], "batch": batch, "direction": "forward", "normalize": "none"}, xr, 2 * p * batch)
+        assert route.split() == ["line32k[N=32768]", "r2c-split"], route
+        want = np.concatenate([oracle.r2c_ref_packed(xr[b * m:(b + 1) * m], m, "none", use_pow2=True) for b in range(batch)])
+        check(oracle, spec, want, "r2c 2^16 over line32k", 8e-4, 8e-4)
+        back, (route, _) = run_plan(fft, dev, {"type": "c2r", "shape": [m], "batch": batch, "direction": "inverse", "normalize": "backward"}, want, m * batch)
+        assert route.split() == ["c2r-split", "line32k[N=32768]"] or route.split() == ["line32k[N=32768]", "c2r-split"], route
+        check(oracle, back, xr, "c2r 2^16 over line32k", 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize("lg,batch", [(15, 3000), (16, 1500), (17, 700), (18, 150), (19, 75), (21, 37)])
-def test_c2c_fused_many_transforms(fft, dev, oracle, lg, batch):
+def test_c2c_fused_many_transforms(fft, dev, oracle, monkeypatch, lg, batch):
     """more transforms than groups: every group walks several transforms and alternates its two workspace slots"""
+    monkeypatch.setenv("MI355FFT_LINE32K", "0")           # keep the solo four-step of 2^15 under test
     n = 1 << lg
     x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
@@ -439,6 +465,7 @@ def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     the workspace slots alternate) and the half-length c2c + split route"""
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     monkeypatch.setenv("MI355FFT_LINES_R2C", "0")        # 2^15 would otherwise be one line-kernel launch (tested in test_r2c_c2r)
+    monkeypatch.setenv("MI355FFT_LINE32K", "0")          # ... and 2^16 the half-length route over the 2^15 line kernel (test_c2c_line32k)
     n = 1 << lg
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 0xE100 + lg).reshape(-1)
@@ -457,6 +484,7 @@ def test_c2r_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     monkeypatch.setenv("MI355FFT_LINES_R2C", "0")
     monkeypatch.setenv("MI355FFT_LINES_C2R", "3")    # 2^15 is a line-kernel launch by default since r02: keep the four-step under test
+    monkeypatch.setenv("MI355FFT_LINE32K", "0")      # 2^16: likewise (half-length route over the 2^15 line kernel)
     n = 1 << lg
     p = n // 2 + 1
     x = oracle.random_real_batch(n, batch, 0xE200 + lg).reshape(-1)

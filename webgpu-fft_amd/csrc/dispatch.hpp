@@ -14,6 +14,7 @@
 #include "kern_lines.hpp"
 #include "kern_mixed.hpp"
 #include "kern_mixed_ct.hpp"
+#include "kern_line32k.hpp"
 #include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
 #include "kern_xcd_res.hpp"
@@ -235,6 +236,15 @@ template <class L> bool launch_mixedct(int id, const MixedArgs& a, unsigned grid
   return false;
 }
 #endif
+// the single-workgroup line of 2^15 points (kern_line32k.hpp); same translation unit as the mixed-radix instances
+template <class L> bool launch_line32k(const MixedArgs& a, unsigned grid, L& l);
+#if defined(MI355_MIXEDCT_DEFINE_INSTANCES) || defined(MI355_HOST_EMU)
+template <class L> bool launch_line32k(const MixedArgs& a, unsigned grid, L& l) {
+  if (a.swap_in) l.launch(fft_line32k_kernel<true>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
+  else l.launch(fft_line32k_kernel<false>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
+  return true;
+}
+#endif
 
 template <class L> bool launch_stage(int radix, const StageArgs& a, unsigned grid, L& l) {
   switch (radix) {
@@ -296,6 +306,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.lines = s.i[0]; a.N = (int)s.i[1]; a.S = s.i[2]; a.T = (int)s.i[3]; a.nst = (int)s.i[4];
       a.swap_in = a.swap_out = (int)s.i[5];
       a.scale = s.f[0];
+      if (s.variant == 1000) return launch_line32k(a, s.grid, l);              // N = 2^15 in one workgroup (kern_line32k.hpp)
       if (s.variant > 0) return launch_mixedct(s.variant - 1, a, s.grid, l);   // compile-time plan: nothing else to pass
       {
         const auto rcp = [](unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; };

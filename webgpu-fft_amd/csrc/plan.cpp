@@ -143,6 +143,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_LINES_TILES_PER_WG")) { const int v = std::atoi(s); if (v >= -1) o.lines_tiles_per_wg = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_FUSED")) o.xcd_fused = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_TRIG_ALT")) o.trig_alt = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_LINE32K")) o.line32k = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RES")) o.xcd_res = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_SPIN_LIMIT")) { const long long v = std::atoll(s); if (v >= 1 && v <= 0x7fffffffll) o.xcd_spin_limit = (unsigned)v; }
   if (const char* s = std::getenv("MI355FFT_XCD_RES_DEPTH")) { const int v = std::atoi(s); if (v == 1 || v == 2 || v == 4) o.xcd_res_depth = v; }
@@ -431,7 +432,10 @@ struct Builder {
   // or the half-length complex FFT + split
   int emit_r2c_even(PtrRef in, PtrRef out, int64_t N, int64_t lines, float scale, std::string& err) {
     if (emit_lines_r2c(in, out, N, lines, scale)) return MI355FFT_OK;   // one launch: split fused behind the last stage (fft_lines_r2c_kernel)
-    if (emit_xcd_r2c(in, out, N, lines, scale)) return MI355FFT_OK;     // one persistent launch: real four-step (kern_xcd_real.hpp)
+    // N = 2^16: the half-length route over the single-workgroup line of 2^15 points measured 318 vs 269 G real points/s for the
+    // real four-step in solo mode (c2r: 318 vs 305)
+    const bool half32k = N == 65536 && opt.line32k && opt.max_line >= 16384 && !opt.force_generic && !opt.only_pass && opt.xcd_fused != 2;
+    if (!half32k && emit_xcd_r2c(in, out, N, lines, scale)) return MI355FFT_OK;     // one persistent launch: real four-step (kern_xcd_real.hpp)
     const int64_t H = N / 2, P = H + 1;
     PtrRef z = alloc_work((uint64_t)lines * H * 8);
     // the real input, read as `lines` complex lines of length H: z[n] = x[2n] + i x[2n+1]
@@ -448,7 +452,8 @@ struct Builder {
   // the mirror: packed spectra -> real lines (unnormalised inverse times `scale`)
   int emit_c2r_even(PtrRef packed, PtrRef out, int64_t N, int64_t lines, float scale, std::string& err) {
     if (emit_lines_r2c(packed, out, N, lines, scale, true)) return MI355FFT_OK;   // pre-split in the first-stage loads (fft_lines_c2r_kernel)
-    if (emit_xcd_r2c(packed, out, N, lines, scale, true)) return MI355FFT_OK;     // Hermitian four-step (kern_xcd_real.hpp)
+    const bool half32k = N == 65536 && opt.line32k && opt.max_line >= 16384 && !opt.force_generic && !opt.only_pass && opt.xcd_fused != 2;
+    if (!half32k && emit_xcd_r2c(packed, out, N, lines, scale, true)) return MI355FFT_OK;     // Hermitian four-step (kern_xcd_real.hpp)
     const int64_t H = N / 2, P = H + 1;
     PtrRef z = alloc_work((uint64_t)lines * H * 8);
     Step& st = push(ST_C2R_PRE);
@@ -542,6 +547,23 @@ struct Builder {
         ir.route += "lines[N=" + std::to_string(N) + "] ";
         return MI355FFT_OK;
       }
+    }
+    // N = 2^15, dense lines: the whole line in the registers of one 512-thread workgroup, exchanges through LDS in halves
+    // (kern_line32k.hpp): one HBM round trip where the solo four-step makes two
+    if (!opt.force_generic && opt.line32k && opt.max_line >= 16384 && S == 1 && N == 32768 && !opt.only_pass && opt.xcd_fused != 2) {
+      std::vector<float2h> t;
+      for (int q = 1; q < 32; ++q) for (int k = 0; k < 32; ++k) t.push_back(root_of_unity((int64_t)q * k, 1024));
+      for (int64_t l = 0; l < 1024; ++l) t.push_back(root_of_unity(l, N));
+      for (int64_t h = 0; h < 32; ++h) t.push_back(root_of_unity(h << 10, N));
+      Step& st = push(ST_LINES_MIXED);
+      st.variant = 1000;
+      st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
+      st.i[0] = lines; st.i[1] = N; st.i[2] = 1; st.i[3] = 1; st.i[4] = 3;
+      st.i[5] = inverse ? 1 : 0; st.i[7] = 512;
+      st.f[0] = scale;
+      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(lines, (int64_t)opt.compute_units));
+      ir.route += "line32k[N=32768] ";
+      return MI355FFT_OK;
     }
     // the column line kernels address a tile with 32-bit element offsets (kern_lines.hpp: voff = idx * S): a strided axis whose
     // plane spans 2^32 elements or more (32 GiB of complex data) stays on the stage route, which indexes with 64 bits

@@ -149,6 +149,7 @@ struct PlannerOptions {
   int xcd_fused = 1;                   // N = N1*N2 with an XCD-fused kernel available: both passes in one persistent launch
   int xcd_shared = 1;                  // 0: no kernel whose workgroups wait for each other (shared-mode XCD kernels); solo instances stay
   unsigned xcd_spin_limit = 4000000u;  // polls before a bounded wait of the XCD kernels gives up (sticky error); tests force 1
+  int line32k = 1;                     // N = 2^15 c2c lines in one workgroup (kern_line32k.hpp) instead of the solo four-step
   int trig_alt = 1;                    // one-launch DCT / DST: use the alternate ROW shapes where the registry has them (ROW_ALT_TRIG)
   int xcd_res = 0;                     // N = 2^20: XCD-resident kernel (kern_xcd_res.hpp): 1 on, 2 = its data-movement skeleton without arithmetic (measurement only)
   int xcd_res_depth = 4;               // exchange channels in flight per XCD (1, 2, 4): 1 MiB of L2-resident buffer each
