@@ -178,16 +178,18 @@ def test_c2c_axes_subset(oracle, shape, axes):
     check(got, _fft_axes_ref(oracle, x, shape, batch, axes, "forward", 1.0), f"axes={axes} in place", 2e-6)
 
 
-@pytest.mark.parametrize("n", [8192, 16384])
-def test_c2c_single_workgroup_long_lines(oracle, n):
+@pytest.mark.parametrize("n,reg", [(8192, 1), (8192, 0), (16384, 0), (16384, 2)])
+def test_c2c_single_workgroup_long_lines(oracle, monkeypatch, n, reg):
     """N = 8192 and 16384 still fit one workgroup's LDS (three stages, the last table read from global memory): one launch,
-    one HBM round trip; r2c / c2r of twice the length ride on them"""
-    batch = 3
+    one HBM round trip; r2c / c2r of twice the length ride on them.  reg: the register-resident form of the same launch
+    (kern_line_reg.hpp: N/64 threads, exchanges through LDS in halves) — the default at 8192, opt-in (2) at 16384"""
+    monkeypatch.setenv("MI355_EMU_LINE32K", str(reg))
+    batch = 5
     x = oracle.random_complex_batch(n, batch, 0xB16 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
         desc = _abi.make_desc("c2c", [n], batch, direction, norm)
         got, route, launches = emu.run_plan(desc, x, x.size)
-        assert route.startswith(f"lines[N={n}]") and launches == 1, route
+        assert route.startswith(f"line-reg[N={n}]" if reg else f"lines[N={n}]") and launches == 1, route
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction}", 2e-6)
     xr = oracle.random_real_batch(2 * n, 2, 0xB17 + n).reshape(-1)
     want = np.concatenate([oracle.r2c_ref_packed(xr[b * 2 * n:(b + 1) * 2 * n], 2 * n, "none") for b in range(2)])

@@ -192,14 +192,16 @@ def test_r2c_c2r_2d_real_images(fft, dev, oracle):
         check(oracle, back, x, f"c2r {shape} ({route.strip()})", 2e-3, 2e-3)
 
 
-@pytest.mark.parametrize("n", [8192, 16384])
-def test_c2c_single_workgroup_long_lines(fft, dev, oracle, n):
-    """N = 8192 / 16384: one workgroup per line, last stage table from global memory — one launch, one HBM round trip"""
-    batch = 37
+@pytest.mark.parametrize("n,reg", [(8192, 1), (8192, 0), (16384, 0), (16384, 2)])
+def test_c2c_single_workgroup_long_lines(fft, dev, oracle, monkeypatch, n, reg):
+    """N = 8192 / 16384: one workgroup per line — in LDS (last stage table from global memory) or, reg != 0, in the registers of N/64
+    threads with the exchanges through LDS in halves (kern_line_reg.hpp; the default at 8192); one launch, one HBM round trip"""
+    monkeypatch.setenv("MI355FFT_LINE32K", str(reg))
+    batch = 37 if reg == 0 else 1500          # more lines than resident workgroups on the register route
     x = oracle.random_complex_batch(n, batch, 0xB16 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward"), ("forward", "unitary")):
         got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
-        assert route.startswith(f"lines[N={n}]") and launches == 1, route
+        assert route.startswith(f"line-reg[N={n}]" if reg else f"lines[N={n}]") and launches == 1, route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"lines {n} {direction} {norm}")
 
 

@@ -14,6 +14,7 @@
 #include "kern_lines.hpp"
 #include "kern_mixed.hpp"
 #include "kern_mixed_ct.hpp"
+#include "kern_line_reg.hpp"
 #include "kern_line32k.hpp"
 #include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
@@ -236,13 +237,23 @@ template <class L> bool launch_mixedct(int id, const MixedArgs& a, unsigned grid
   return false;
 }
 #endif
-// the single-workgroup line of 2^15 points (kern_line32k.hpp); same translation unit as the mixed-radix instances
-template <class L> bool launch_line32k(const MixedArgs& a, unsigned grid, L& l);
+// lines of 2^13 / 2^14 / 2^15 points held in the registers of one workgroup (kern_line_reg.hpp); same translation unit as the
+// mixed-radix instances.  lg = log2 N.
+template <class L> bool launch_line_reg(int lg, const MixedArgs& a, unsigned grid, L& l);
 #if defined(MI355_MIXEDCT_DEFINE_INSTANCES) || defined(MI355_HOST_EMU)
-template <class L> bool launch_line32k(const MixedArgs& a, unsigned grid, L& l) {
-  if (a.swap_in) l.launch(fft_line32k_kernel<true>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
-  else l.launch(fft_line32k_kernel<false>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
-  return true;
+template <class C, class L> void launch_line_reg_cfg(const MixedArgs& a, unsigned grid, L& l) {
+  if (a.swap_in) l.launch(fft_line_reg_kernel<C, true>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a);
+  else l.launch(fft_line_reg_kernel<C, false>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a);
+}
+template <class L> bool launch_line_reg(int lg, const MixedArgs& a, unsigned grid, L& l) {
+  if (lg == 13) { launch_line_reg_cfg<LineRegCfg<8192, 16, 16>>(a, grid, l); return true; }
+  if (lg == 14) { launch_line_reg_cfg<LineRegCfg<16384, 32, 16>>(a, grid, l); return true; }
+  if (lg == 15) {   // the dedicated form of the same scheme (kern_line32k.hpp): the generic template spills 344 B per lane at this size (177 vs 288 GPoints/s)
+    if (a.swap_in) l.launch(fft_line32k_kernel<true>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
+    else l.launch(fft_line32k_kernel<false>, grid, (unsigned)Line32kCfg::THREADS, (unsigned)Line32kCfg::LDS_BYTES, a);
+    return true;
+  }
+  return false;
 }
 #endif
 
@@ -306,7 +317,7 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.lines = s.i[0]; a.N = (int)s.i[1]; a.S = s.i[2]; a.T = (int)s.i[3]; a.nst = (int)s.i[4];
       a.swap_in = a.swap_out = (int)s.i[5];
       a.scale = s.f[0];
-      if (s.variant == 1000) return launch_line32k(a, s.grid, l);              // N = 2^15 in one workgroup (kern_line32k.hpp)
+      if (s.variant >= 1000) return launch_line_reg(s.variant - 1000, a, s.grid, l);   // 2^13 .. 2^15 in one workgroup's registers (kern_line_reg.hpp)
       if (s.variant > 0) return launch_mixedct(s.variant - 1, a, s.grid, l);   // compile-time plan: nothing else to pass
       {
         const auto rcp = [](unsigned d) { return d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u; };

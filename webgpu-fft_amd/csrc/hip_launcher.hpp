@@ -78,7 +78,7 @@ extern template bool launch_lines_family<FAM_PASS_A, HipLauncher>(int, const Lin
 extern template bool launch_lines_family<FAM_PASS_B, HipLauncher>(int, const LineArgs&, unsigned, HipLauncher&);
 
 extern template bool launch_mixedct<HipLauncher>(int, const MixedArgs&, unsigned, HipLauncher&);
-extern template bool launch_line32k<HipLauncher>(const MixedArgs&, unsigned, HipLauncher&);
+extern template bool launch_line_reg<HipLauncher>(int, const MixedArgs&, unsigned, HipLauncher&);
 extern template bool launch_xcd_res<HipLauncher>(int, const XcdFusedArgs&, unsigned, HipLauncher&);
 
 }  // namespace mi355

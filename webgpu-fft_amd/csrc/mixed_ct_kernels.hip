@@ -3,5 +3,5 @@
 #include "hip_launcher.hpp"
 namespace mi355 {
 template bool launch_mixedct<HipLauncher>(int, const MixedArgs&, unsigned, HipLauncher&);
-template bool launch_line32k<HipLauncher>(const MixedArgs&, unsigned, HipLauncher&);
+template bool launch_line_reg<HipLauncher>(int, const MixedArgs&, unsigned, HipLauncher&);
 }

@@ -534,6 +534,29 @@ struct Builder {
       return MI355FFT_OK;
     }
     const bool p2 = is_pow2(N);
+    // N = 2^15 and 2^13 (line32k >= 1; 2^14 too with line32k == 2: measured equal to its ROW kernel), dense lines: the whole line in the
+    // registers of one workgroup of N/64 threads, exchanges through LDS in halves (kern_line32k.hpp, kern_line_reg.hpp).  2^15: one HBM
+    // round trip where the solo four-step makes two (288 vs 210 GPoints/s); 2^13: four 128-thread workgroups per CU instead of two
+    // 256-thread ones with the line in LDS (330 vs 288)
+    if (!opt.force_generic && opt.max_line >= 16384 && S == 1 && !opt.only_pass && opt.xcd_fused != 2 &&
+        ((opt.line32k >= 1 && (N == 32768 || N == 8192)) || (opt.line32k == 2 && N == 16384))) {
+      const int lg = lg2(N);
+      const int R0 = 32, R1 = N == 8192 ? 16 : 32;
+      std::vector<float2h> t;
+      for (int q = 1; q < R1; ++q) for (int k = 0; k < R0; ++k) t.push_back(root_of_unity((int64_t)q * k, (int64_t)R0 * R1));
+      for (int64_t l = 0; l < 1024; ++l) t.push_back(root_of_unity(l, N));
+      for (int64_t h = 0; h < N / 1024; ++h) t.push_back(root_of_unity(h << 10, N));
+      Step& st = push(ST_LINES_MIXED);
+      st.variant = 1000 + lg;
+      st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
+      st.i[0] = lines; st.i[1] = N; st.i[2] = 1; st.i[3] = 1; st.i[4] = 3;
+      st.i[5] = inverse ? 1 : 0; st.i[7] = N / 64;
+      st.f[0] = scale;
+      const int64_t per_cu = N == 32768 ? 1 : (N == 16384 ? 2 : 4);
+      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(lines, (int64_t)opt.compute_units * per_cu));
+      ir.route += (N == 32768 ? std::string("line32k[N=32768] ") : "line-reg[N=" + std::to_string(N) + "] ");
+      return MI355FFT_OK;
+    }
     if (!opt.force_generic && S == 1 && p2 && N <= opt.max_line && !(opt.xcd_fused == 2 && N == 4096)) {   // xcd_fused == 2: emulation tests
       const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
       if (m) {
@@ -547,23 +570,6 @@ struct Builder {
         ir.route += "lines[N=" + std::to_string(N) + "] ";
         return MI355FFT_OK;
       }
-    }
-    // N = 2^15, dense lines: the whole line in the registers of one 512-thread workgroup, exchanges through LDS in halves
-    // (kern_line32k.hpp): one HBM round trip where the solo four-step makes two
-    if (!opt.force_generic && opt.line32k && opt.max_line >= 16384 && S == 1 && N == 32768 && !opt.only_pass && opt.xcd_fused != 2) {
-      std::vector<float2h> t;
-      for (int q = 1; q < 32; ++q) for (int k = 0; k < 32; ++k) t.push_back(root_of_unity((int64_t)q * k, 1024));
-      for (int64_t l = 0; l < 1024; ++l) t.push_back(root_of_unity(l, N));
-      for (int64_t h = 0; h < 32; ++h) t.push_back(root_of_unity(h << 10, N));
-      Step& st = push(ST_LINES_MIXED);
-      st.variant = 1000;
-      st.p[0] = src; st.p[1] = dst; st.p[2] = add_table(t);
-      st.i[0] = lines; st.i[1] = N; st.i[2] = 1; st.i[3] = 1; st.i[4] = 3;
-      st.i[5] = inverse ? 1 : 0; st.i[7] = 512;
-      st.f[0] = scale;
-      st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(lines, (int64_t)opt.compute_units));
-      ir.route += "line32k[N=32768] ";
-      return MI355FFT_OK;
     }
     // the column line kernels address a tile with 32-bit element offsets (kern_lines.hpp: voff = idx * S): a strided axis whose
     // plane spans 2^32 elements or more (32 GiB of complex data) stays on the stage route, which indexes with 64 bits
