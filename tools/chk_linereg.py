@@ -3,7 +3,7 @@ sys.path.insert(0, "webgpu-fft_amd/python"); sys.path.insert(0, "tests")
 import torch, mi355fft
 dev = mi355fft.Device(0)
 rng = np.random.default_rng(7)
-for n in (8192, 16384, 32768):
+for n in (4096, 8192, 16384, 32768):
     batch = 37
     x = (rng.random(2 * n * batch, dtype=np.float32) - 0.5).astype(np.float32)
     z = x.astype(np.float64).reshape(batch, n, 2); z = z[..., 0] + 1j * z[..., 1]

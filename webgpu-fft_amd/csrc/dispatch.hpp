@@ -246,6 +246,7 @@ template <class C, class L> void launch_line_reg_cfg(const MixedArgs& a, unsigne
   else l.launch(fft_line_reg_kernel<C, false>, grid, (unsigned)C::THREADS, (unsigned)C::LDS_BYTES, a);
 }
 template <class L> bool launch_line_reg(int lg, const MixedArgs& a, unsigned grid, L& l) {
+  if (lg == 12) { launch_line_reg_cfg<LineRegCfg<4096, 16, 8>>(a, grid, l); return true; }
   if (lg == 13) { launch_line_reg_cfg<LineRegCfg<8192, 16, 16>>(a, grid, l); return true; }
   if (lg == 14) { launch_line_reg_cfg<LineRegCfg<16384, 32, 16>>(a, grid, l); return true; }
   if (lg == 15) {   // the dedicated form of the same scheme (kern_line32k.hpp): the generic template spills 344 B per lane at this size (177 vs 288 GPoints/s)

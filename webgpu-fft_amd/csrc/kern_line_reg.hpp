@@ -22,7 +22,7 @@ namespace mi355 {
 template <int N_, int R1_, int R2_>
 struct LineRegCfg {
   static constexpr int N = N_, R0 = 32, R1 = R1_, R2 = R2_;
-  static_assert(R0 * R1 * R2 == N && (R1 == 16 || R1 == 32) && (R2 == 16 || R2 == 32), "radix plan");
+  static_assert(R0 * R1 * R2 == N && (R1 == 16 || R1 == 32) && (R2 == 8 || R2 == 16 || R2 == 32), "radix plan");
   static constexpr int VPT = 64, THREADS = N / VPT;
   static constexpr int NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
   static constexpr int BPT0 = VPT / R0, BPT1 = VPT / R1, BPT2 = VPT / R2;

@@ -539,9 +539,9 @@ struct Builder {
     // round trip where the solo four-step makes two (288 vs 210 GPoints/s); 2^13: four 128-thread workgroups per CU instead of two
     // 256-thread ones with the line in LDS (330 vs 288)
     if (!opt.force_generic && opt.max_line >= 16384 && S == 1 && !opt.only_pass && opt.xcd_fused != 2 &&
-        ((opt.line32k >= 1 && (N == 32768 || N == 8192)) || (opt.line32k == 2 && N == 16384))) {
+        ((opt.line32k >= 1 && (N == 32768 || N == 8192)) || (opt.line32k == 2 && (N == 16384 || N == 4096)))) {
       const int lg = lg2(N);
-      const int R0 = 32, R1 = N == 8192 ? 16 : 32;
+      const int R0 = 32, R1 = N <= 8192 ? 16 : 32;
       std::vector<float2h> t;
       for (int q = 1; q < R1; ++q) for (int k = 0; k < R0; ++k) t.push_back(root_of_unity((int64_t)q * k, (int64_t)R0 * R1));
       for (int64_t l = 0; l < 1024; ++l) t.push_back(root_of_unity(l, N));
@@ -552,7 +552,7 @@ struct Builder {
       st.i[0] = lines; st.i[1] = N; st.i[2] = 1; st.i[3] = 1; st.i[4] = 3;
       st.i[5] = inverse ? 1 : 0; st.i[7] = N / 64;
       st.f[0] = scale;
-      const int64_t per_cu = N == 32768 ? 1 : (N == 16384 ? 2 : 4);
+      const int64_t per_cu = N == 32768 ? 1 : (N == 16384 ? 2 : (N == 8192 ? 4 : 8));
       st.grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(lines, (int64_t)opt.compute_units * per_cu));
       ir.route += (N == 32768 ? std::string("line32k[N=32768] ") : "line-reg[N=" + std::to_string(N) + "] ");
       return MI355FFT_OK;
