@@ -156,7 +156,7 @@ struct PlannerOptions {
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
-  int solo_cap_mb = 1024;              // solo mode: all workgroups' workspace slots together (MiB); occupancy matters more than the footprint
+  int solo_cap_mb = 256;               // solo mode: all workgroups' workspace slots together (MiB) = the Infinity Cache (r02: 2^16 203 vs 189 GPoints/s with 1024; below 256 occupancy collapses)
   int solo_max_kb = 1024;              // transforms up to this size run in solo mode
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_ct = 1;                    // mixed-radix lengths with a compile-time-plan instance (kern_mixed_ct.hpp) use it (dense lines)
