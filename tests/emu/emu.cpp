@@ -160,6 +160,7 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   if (const char* e = std::getenv("MI355_EMU_TRIG_FUSED")) opt.trig_fused = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_TRIG_ALT")) opt.trig_alt = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_LINE32K")) opt.line32k = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_SOLO_MAX_KB")) opt.solo_max_kb = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_CONV_LINES")) opt.conv_lines = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_CONV_FUSED_MAX_POINTS")) opt.conv_fused_max_points = std::atoll(e);
   emu::g_xcds = std::getenv("MI355_EMU_XCDS") ? (unsigned)std::atoi(std::getenv("MI355_EMU_XCDS")) : 2u;

@@ -452,6 +452,7 @@ def test_real_four_step_solo_sizes(oracle, monkeypatch, lg, label):
     monkeypatch.setenv("MI355_EMU_LINES_R2C", "0")       # 2^15 would otherwise be a single line kernel launch
     monkeypatch.setenv("MI355_EMU_LINES_C2R", "3")       # ... on the c2r side too since r02 (3: line kernel up to N = 2^14 only)
     monkeypatch.setenv("MI355_EMU_LINE32K", "0")         # 2^16 real would otherwise take the half-length route over the 2^15 line kernel
+    monkeypatch.setenv("MI355_EMU_SOLO_MAX_KB", "1024")  # r2c 2^17 runs shared (XCD groups) by default since r02
     monkeypatch.setenv("MI355_EMU_CUS", "3")
     monkeypatch.setenv("MI355_EMU_MAX_GRID", "3")
     n, batch = 1 << lg, 7
@@ -570,6 +571,7 @@ def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
     workgroup synchronisation); more transforms than workgroups so that every slot is re-used"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_LINE32K", "0")              # 2^15 is a single-workgroup line by default (kern_line32k.hpp)
+    monkeypatch.setenv("MI355_EMU_SOLO_MAX_KB", "1024")       # 2^17 runs shared (XCD groups) by default since r02
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_MAX_GRID", str(cus))        # fewer workgroups than transforms
     n, batch = 1 << lg, 7

@@ -135,6 +135,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
     monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # ... and so would 2^15 (kern_line32k.hpp, test_c2c_line32k)
+    monkeypatch.setenv("MI355FFT_SOLO_MAX_KB", "1024")    # solo mode up to 2^17 as in round 1 (default since r02: up to 2^16, 2^17 shared)
     n, batch = 1 << lg, 3 if lg <= 18 else 2
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
@@ -233,6 +234,7 @@ def test_c2c_line32k(fft, dev, oracle, batch):
 def test_c2c_fused_many_transforms(fft, dev, oracle, monkeypatch, lg, batch):
     """more transforms than groups: every group walks several transforms and alternates its two workspace slots"""
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # keep the solo four-step of 2^15 under test
+    monkeypatch.setenv("MI355FFT_SOLO_MAX_KB", "1024")    # ... and of 2^17 (shared by default since r02)
     n = 1 << lg
     x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):

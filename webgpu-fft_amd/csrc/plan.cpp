@@ -306,7 +306,7 @@ struct Builder {
     const int64_t N = N0 * N1;
     const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, false, false, false, 0);
-    const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10);
+    const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb_2d << 10);
     if (!solo && !opt.xcd_shared) return false;
     int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
     PtrRef wslots, ctl;
@@ -348,7 +348,7 @@ struct Builder {
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
     const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
     // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
-    const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / 2 && opt.xcd_fused != 2;
+    const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / (c2r ? 1 : 2) && opt.xcd_fused != 2;
     if (!solo && !opt.xcd_shared) return false;
     int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
     PtrRef wslots, ctl;

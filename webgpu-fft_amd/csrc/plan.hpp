@@ -157,7 +157,9 @@ struct PlannerOptions {
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int solo_cap_mb = 256;               // solo mode: all workgroups' workspace slots together (MiB) = the Infinity Cache (r02: 2^16 203 vs 189 GPoints/s with 1024; below 256 occupancy collapses)
-  int solo_max_kb = 1024;              // transforms up to this size run in solo mode
+  int solo_max_kb_2d = 1024;           // 2-D planes up to this size run in solo mode (unchanged from round 1)
+  int solo_max_kb = 512;               // c2c transforms (and 2-D planes) up to this size run in solo mode; r2c up to half of it, c2r up to this many KB of REAL line
+                                       // (r02, same box: c2c 2^17 shared 171 vs solo 147, r2c 2^17 281 vs 250, c2r 2^17 solo 318 vs 278, c2c 2^16 solo 206 vs 156)
   int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
   int mixed_ct = 1;                    // mixed-radix lengths with a compile-time-plan instance (kern_mixed_ct.hpp) use it (dense lines)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
