@@ -287,15 +287,19 @@ def test_c2c_nd(oracle, shape):
         check(got, oracle.c2c_ref_batch(x, shape, batch, direction, "unitary"), f"nd {shape} {direction}")
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.parametrize("n", [17, 29, 34, 97, 2039])
-def test_c2c_bluestein_lengths(oracle, n):
-    """lengths with a prime factor > 13 (the reference's own test sizes: complete.suite.js:664-676) run the chirp-z route"""
-    batch = 3
+def test_c2c_bluestein_lengths(oracle, monkeypatch, n, fused):
+    """lengths with a prime factor > 13 (the reference's own test sizes: complete.suite.js:664-676) run the chirp-z route.
+    fused=1 (default): two line-kernel launches — chirp + zero-padded embed on the forward launch's loads, the product with the
+    chirp's spectrum on its last-stage store, chirp + crop on the inverse launch's store pass; fused=0: the five-launch form"""
+    monkeypatch.setenv("MI355_EMU_FUSE_VIEWS", str(fused))
+    batch = 5
     x = oracle.random_complex_batch(n, batch, 0xC100 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
         desc = _abi.make_desc("c2c", [n], batch, direction, norm)
-        got, route, _ = emu.run_plan(desc, x, x.size)
-        assert "bluestein[" in route
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert (route.startswith("bluestein-lines[") and launches == 2) if fused else ("bluestein[" in route and launches >= 5), route
         want = oracle.c2c_ref_batch(x, [n], batch, direction, norm)
         l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
         assert l2 <= 1e-5 and mx <= 2e-5, f"bluestein N={n} {direction}: {l2:.2e} {mx:.2e}"
@@ -308,7 +312,7 @@ def test_c2c_nd_with_bluestein_axes(oracle, shape):
     x = oracle.random_complex_batch(n, batch, 0xD200 + n).reshape(-1)
     desc = _abi.make_desc("c2c", shape, batch, "forward", "unitary")
     got, route, _ = emu.run_plan(desc, x, x.size)
-    assert "bluestein[" in route
+    assert "bluestein[" in route or "bluestein-lines[" in route
     check(got, oracle.c2c_ref_batch(x, shape, batch, "forward", "unitary"), f"nd bluestein {shape}", 2e-5)
 
 

@@ -300,14 +300,19 @@ def test_c2c_nd_mixed_radix(fft, dev, oracle, shape):
         check(oracle, got, oracle.c2c_ref_batch(x, shape, batch, direction, norm), f"{shape} {direction} {route}", 3e-3, 3e-3)
 
 
-@pytest.mark.parametrize("n", [17, 29, 34, 97, 2039, 100003])
-def test_c2c_bluestein_lengths(fft, dev, oracle, n):
-    """the reference's own prime test sizes (complete.suite.js:664-676) through the chirp-z route"""
-    batch = 3 if n < 10000 else 1
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("n", [17, 29, 34, 97, 2039, 6007, 100003])
+def test_c2c_bluestein_lengths(fft, dev, oracle, monkeypatch, n, fused):
+    """the reference's own prime test sizes (complete.suite.js:664-676) through the chirp-z route; fused=1: two line-kernel launches
+    (chirp, embed and product on the forward launch, chirp and crop on the inverse one) up to a convolution length of 16384"""
+    if not fused and n == 6007:
+        pytest.skip("one long case on the five-launch form is enough")
+    monkeypatch.setenv("MI355FFT_FUSE_VIEWS", str(fused))
+    batch = 300 if n < 10000 else 1
     x = oracle.random_complex_batch(n, batch, 0xC100 + n).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
-        got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
-        assert "bluestein[" in route
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm}, x, x.size)
+        assert (route.startswith("bluestein-lines[") and launches == 2) if (fused and n < 10000) else "bluestein[" in route, route
         if n < 10000:
             want = oracle.c2c_ref_batch(x, [n], batch, direction, norm)
         else:  # O(N^2) oracle is infeasible: independent f64 FFT

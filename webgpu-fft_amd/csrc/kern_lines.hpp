@@ -431,6 +431,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
         for (int q = 0; q < C::N; ++q) {
           if (q < slo || q >= shi) continue;
           cf r = cswap_if<C::SWAP_OUT>(v[q] * a.scale);
+          if (a.fs_lo_mask & 1u) { r = cmul(r, a.tw_hi[q]); if (a.fs_lo_mask & 2u) r = r.yx; }   // Bluestein: chirp on the way out
           if (zero || q < zlo || q >= zhi) r = cf{0.0f, 0.0f};
           a.out[base + (long long)q * so] = r;
         }
@@ -457,6 +458,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
         for (int idx = u; idx < C::N; idx += C::TPL) {
           if (idx < slo || idx >= shi) continue;
           cf r = cswap_if<C::SWAP_OUT>(lds[lds_index<C>(line, idx)] * a.scale);
+          if (a.fs_lo_mask & 1u) { r = cmul(r, a.tw_hi[idx]); if (a.fs_lo_mask & 2u) r = r.yx; }   // Bluestein: chirp on the way out
           if (zero || idx < zlo || idx >= zhi) r = cf{0.0f, 0.0f};
           a.out[base + (long long)idx * so] = r;
         }
@@ -728,7 +730,11 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
         for (int q = 0; q < I0::R; ++q) {
           const int idx = u + b * C::TPL + q * (C::N / I0::R);
           cf x = {0.0f, 0.0f};
-          if (ok && idx >= lo && idx < hi) x = a.in[base + (long long)idx * sa];
+          if (ok && idx >= lo && idx < hi) {
+            x = a.in[base + (long long)idx * sa];
+            // Bluestein (plan.cpp emit_bluestein): the chirp a.tw_hi[n] rides the load (bit 1: the swap that turns the route into an inverse)
+            if (a.fs_lo_mask & 1u) { if (a.fs_lo_mask & 2u) x = x.yx; x = cmul(x, a.tw_hi[idx]); }
+          }
           v[b * I0::R + q] = x;
         }
       }

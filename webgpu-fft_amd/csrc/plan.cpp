@@ -844,6 +844,41 @@ struct Builder {
       lin_src = tr; lin_dst = tr;
     }
     const PtrRef y = alloc_work((uint64_t)lines * M * 8);
+    // r02: with the convolution length on a line kernel the five launches become two — the chirp and the zero-padded embed ride the
+    // first-stage loads of the forward launch, the product with the chirp's spectrum its last-stage store (fft_lines_mul_kernel<C, MAPPED>),
+    // and the inverse launch multiplies by the chirp and crops to N points in its store pass (fft_lines_mapped_kernel)
+    {
+      const LineKernelMeta* mf = nullptr;
+      if (opt.fuse_views && opt.conv_lines && !opt.force_generic && S == 1 && M >= 64 && M <= opt.max_line && M * 2 < ((int64_t)1 << 31) &&
+          !(opt.xcd_fused == 2 && M == 4096))
+        mf = find_line_kernel((int)M, false, false, false, false, 0);
+      const LineKernelMeta* mi = mf ? find_line_kernel((int)M, false, false, true, true, 0) : nullptr;
+      if (mf && mi && mf->lds_bytes > 0 && mf->R1 > 1) {
+        const int64_t one[1] = {M};
+        SideMap win = dense_map(one, 1);          // N live points of an M-point line, lines N apart
+        win.hi[0] = (int)N; win.batch_stride = N; win.ax = 0;
+        const SideMap full = dense_map(one, 1);
+        const int64_t flags = 1 | (inverse ? 2 : 0);
+        Step& f = push(ST_LINES);
+        f.variant = mf->id;
+        f.p[0] = lin_src; f.p[1] = y; f.p[2] = line_tables(*mf); f.p[3] = tb; f.p[4] = tchirp;
+        int64_t tiles = (lines + mf->T - 1) / mf->T;
+        f.i[0] = tiles; f.i[1] = lines; f.i[2] = 1; f.i[3] = M; f.i[4] = 1; f.i[5] = M; f.i[6] = 0; f.i[7] = flags; f.i[9] = 4; f.i[10] = 1;
+        f.f[0] = 1.0f;
+        f.imap = win; f.omap = full;
+        f.grid = lines_grid(*mf, tiles);
+        Step& g = push(ST_LINES);
+        g.variant = mi->id;
+        g.p[0] = y; g.p[1] = lin_dst; g.p[2] = line_tables(*mi); g.p[4] = tchirp;
+        tiles = (lines + mi->T - 1) / mi->T;
+        g.i[0] = tiles; g.i[1] = lines; g.i[2] = 1; g.i[3] = M; g.i[4] = 1; g.i[5] = M; g.i[7] = flags; g.i[10] = 1;
+        g.f[0] = (float)((double)scale / (double)M);
+        g.imap = full; g.omap = win;
+        g.grid = lines_grid(*mi, tiles);
+        ir.route += "bluestein-lines[N=" + std::to_string(N) + ",M=" + std::to_string(M) + "] ";
+        return MI355FFT_OK;
+      }
+    }
     Step& pre = push(ST_CHIRP_PRE);
     pre.p[0] = lin_src; pre.p[1] = y; pre.p[2] = tchirp;
     pre.i[0] = N; pre.i[1] = M; pre.i[2] = lines; pre.i[3] = inverse ? 1 : 0; pre.i[4] = 0;
