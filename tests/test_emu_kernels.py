@@ -411,6 +411,25 @@ def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     check(got, want, f"xcd-r2c {label}", 1e-5)
 
 
+@pytest.mark.parametrize("cus,xcds,split,slots,norm", [(2, 2, 1, 2, "none"), (3, 1, 1, 1, "unitary"), (4, 1, 2, 2, "backward")])
+def test_r2c_xcd_regtile(oracle, monkeypatch, cus, xcds, split, slots, norm):
+    """config 5's line (r2c N = 2^22) as a real four-step on register tiles (kern_regtile.hpp fft_xcd_rt_r2c_kernel): the
+    separation of the two real columns of a complex column in the registers of the thread that owns both mirror consumers,
+    65 row tiles (the last with one live row), Hermitian-mirrored stores incl. the Nyquist bin"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
+    n, batch = 1 << 22, 3
+    x = oracle.random_real_batch(n, batch, 0xD122 + cus).reshape(-1)
+    want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm) for b in range(batch)])
+    desc = _abi.make_desc("r2c", [n], batch, "forward", norm)
+    got, route, launches = emu.run_plan(desc, x, batch * (n // 2 + 1) * 2)
+    assert route.startswith("xcd-r2c-rt[N=2048x2048]") and launches == 2, route
+    check(got, want, f"xcd-r2c-rt {norm}", 1e-5)
+
+
 @pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (6, 3, 1, 1), (8, 2, 2, 2), (9, 1, 8, 2)])
 def test_c2r_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     """Hermitian four-step c2r in one persistent launch (kern_xcd_real.hpp), test instance 64 x 64"""
@@ -567,6 +586,25 @@ def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     desc = _abi.make_desc("c2c", [n], batch, "forward", "unitary", in_place=True)
     got, route, _ = emu.run_plan(desc, x, x.size)
     check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")
+
+
+@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(21, "1024x2048", 2, 2, 1, 2), (21, "1024x2048", 3, 1, 1, 1), (22, "2048x2048", 2, 1, 1, 2), (22, "2048x2048", 4, 2, 2, 2)])
+def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots):
+    """2048-point sides on register-resident 16-line tiles (kern_regtile.hpp): 64-point DFT in registers, one exchange through LDS in
+    two halves, radix-32 stage; 2^21 = LDS-resident pass A + register-tile pass B, 2^22 = register tiles on both passes.
+    MI355_EMU_XCD_RT=0 is the route it replaces (8-line LDS tiles / two-pass)."""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
+    n, batch = 1 << lg, 3
+    x = oracle.random_complex_batch(n, batch, 0x2700 + lg).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith(f"xcd-fused-rt[N={label}]") and launches == 2, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-rt {label} {direction}")
 
 
 @pytest.mark.parametrize("lg,label,cus", [(15, "128x256", 3), (16, "256x256", 2), (17, "256x512", 5)])

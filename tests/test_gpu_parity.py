@@ -123,16 +123,17 @@ def test_c2c_in_place_and_offsets(fft, dev, oracle):
     out.destroy()
 
 
-FUSED_LG = (15, 16, 17, 18, 19, 20, 21)   # 15-17: solo mode; 2^22 stays on the two-launch route   # MI355_XCD_KERNEL_LIST (plan.hpp)
+FUSED_LG = (15, 16, 17, 18, 19, 20, 21, 22)   # 15-17: solo mode; 21, 22 (r03): register-tile instances   # MI355_XCD_KERNEL_LIST / MI355_XCD_RT_KERNEL_LIST (plan.hpp)
 
 
-@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 @pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     """four-step sizes on both routes: the two-launch route and (where an instance exists) the XCD-fused launch"""
-    if fused and lg not in FUSED_LG:
+    if fused and lg not in FUSED_LG or (fused == 2 and lg != 21):
         pytest.skip("no fused instance")
-    monkeypatch.setenv("MI355FFT_XCD_FUSED", str(fused))
+    monkeypatch.setenv("MI355FFT_XCD_FUSED", str(min(fused, 1)))
+    monkeypatch.setenv("MI355FFT_XCD_RT", "0" if fused == 2 else "1")   # fused=2: the LDS-resident 1024 x 2048 instance the register tiles replaced (8-line tiles)
     monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # ... and so would 2^15 (kern_line32k.hpp, test_c2c_line32k)
     monkeypatch.setenv("MI355FFT_SOLO_MAX_KB", "1024")    # solo mode up to 2^17 as in round 1 (default since r02: up to 2^16, 2^17 shared)
@@ -140,7 +141,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused[") if fused else "two-pass["), route
+        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused-rt[" if lg >= 21 and fused == 1 else "xcd-fused[") if fused else "two-pass["), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
@@ -230,7 +231,7 @@ def test_c2c_line32k(fft, dev, oracle, batch):
         check(oracle, back, xr, "c2r 2^16 over line32k", 2e-3, 2e-3)
 
 
-@pytest.mark.parametrize("lg,batch", [(15, 3000), (16, 1500), (17, 700), (18, 150), (19, 75), (21, 37)])
+@pytest.mark.parametrize("lg,batch", [(15, 3000), (16, 1500), (17, 700), (18, 150), (19, 75), (21, 37), (22, 19)])
 def test_c2c_fused_many_transforms(fft, dev, oracle, monkeypatch, lg, batch):
     """more transforms than groups: every group walks several transforms and alternates its two workspace slots"""
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # keep the solo four-step of 2^15 under test
@@ -239,7 +240,7 @@ def test_c2c_fused_many_transforms(fft, dev, oracle, monkeypatch, lg, batch):
     x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
-        assert (route.startswith("xcd-solo[") and launches == 1) if lg <= 17 else (route.startswith("xcd-fused[") and launches == 2), route
+        assert (route.startswith("xcd-solo[") and launches == 1) if lg <= 17 else (route.startswith("xcd-fused-rt[" if lg >= 21 else "xcd-fused[") and launches == 2), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"fused 2^{lg} x{batch} {direction}")
 
 
@@ -480,7 +481,7 @@ def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     x = oracle.random_real_batch(n, batch, 0xE100 + lg).reshape(-1)
     for norm in ("none", "unitary"):
         got, (route, launches) = run_plan(fft, dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": norm}, x, 2 * p * batch)
-        assert route.startswith("xcd-r2c") == bool(fused and lg <= 21), route   # 2^22: half-length route over the fused c2c kernel
+        assert route.startswith("xcd-r2c-rt[" if lg == 22 else "xcd-r2c") == bool(fused), route   # 2^22 (r03): real four-step on register tiles (kern_regtile.hpp)
         want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm, use_pow2=True) for b in range(batch)])
         check(oracle, got, want, f"r2c 2^{lg} {norm} ({route.strip()})", 8e-4, 8e-4)
 

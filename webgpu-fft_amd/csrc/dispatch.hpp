@@ -18,6 +18,7 @@
 #include "kern_line32k.hpp"
 #include "kern_trig.hpp"
 #include "kern_xcd_real.hpp"
+#include "kern_regtile.hpp"
 #include "kern_xcd_res.hpp"
 #include "plan.hpp"
 
@@ -142,7 +143,7 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
 #define MI_XCD_PLUS2(...) +2
 #define MI_XCD_PLUS1(...) +1
 constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1)
-                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2);
+                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_RT_KERNEL_LIST(MI_XCD_PLUS2) + 1;   // + the register-tile r2c 2048 x 2048
 #undef MI_XCD_PLUS2
 #undef MI_XCD_PLUS1
 
@@ -183,6 +184,28 @@ template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, 
   MI355_XCD_2D_KERNEL_LIST(X)
 #undef X
 #undef MI_XCD_B_OUT_COL
+  // register-tile instances (kern_regtile.hpp): forward, then inverse, per entry
+#define MI_XCD_RT_CASE(N1, INV)                                                                                   \
+  {                                                                                                               \
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;                                                         \
+    if constexpr (ONLY < 0 || ONLY == ME) {                                                                       \
+      if (id == ME) {                                                                                             \
+        using F = XcdRtCfg<N1, INV>;                                                                              \
+        l.launch_concurrent(fft_xcd_rt_kernel<N1, INV>, grid, (unsigned)F::THREADS, (unsigned)F::LDS_BYTES, a);   \
+        return true;                                                                                              \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+#define X(N1) MI_XCD_RT_CASE(N1, false) MI_XCD_RT_CASE(N1, true)
+  MI355_XCD_RT_KERNEL_LIST(X)
+#undef X
+#undef MI_XCD_RT_CASE
+  {
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;
+    if constexpr (ONLY < 0 || ONLY == ME) {
+      if (id == ME) { l.launch_concurrent(fft_xcd_rt_r2c_kernel<2048>, grid, (unsigned)XcdRtR2cCfg::THREADS, (unsigned)XcdRtR2cCfg::LDS_BYTES, a); return true; }
+    }
+  }
   static_assert(__COUNTER__ - MI_XCD_COUNTER_BASE == XCD_INSTANCE_COUNT, "instance ids out of step with the lists");
   return false;
 }

@@ -1,0 +1,392 @@
+// kern_regtile.hpp — four-step passes over 2048-point sides on REGISTER-resident tiles of 16 lines (r03).
+//
+// Why: a 16 x 2048 tile is 2^15 points = 256 KB, more than the 160 KB of LDS, so the LDS-resident PASS_A / PASS_B kernels of
+// kern_lines.hpp take 2048-point sides as 8-line tiles — 64-byte segments on their strided side, which the fabric moves 15-20 %
+// slower than 128-byte ones (profiles/r02_size_sweep.log: c2c 2^21 163, 2^22 112 GPoints/s against 176-190 for 2^18 .. 2^20).
+// Here the tile lives in the registers of a 512-thread workgroup (64 values per thread, the scheme of kern_line32k.hpp) and only
+// the ONE exchange of the plan 2048 = 64 * 32 goes through LDS, in two halves of 128 KB:
+//   stage 0+1  a thread owns (line, u), u = 0..31: inputs x[u + 32 m], m = 0..63, and forms their 64-point DFT in registers
+//              (32 radix-2 butterflies, the odd half times e^{-2 pi i m/64} — literals —, two radix-32 DFTs): output p of producer
+//              u is element 64 u + p of the Stockham intermediate;
+//   exchange   consumer butterfly j2 = p (0..63) of the same line reads element j2 + 64 q2 = output p of producer u = q2: the
+//              outputs p < 32 of every producer travel first, then p >= 32, so a thread owns one consumer per half;
+//   stage 2    radix 32 with roots e^{-2 pi i q2 j2/2048} from an LDS table, outputs at j2 + 64 q.
+// Replaces, for these sides, the reference's per-stage passes (src/kernels/stockham_stage.js:17-106) and its transposes
+// (src/kernels/transpose.js:1-51, src/plan.js:375-384) exactly as the LDS-resident passes do: the transposes are the address maps.
+//
+// Thread maps (every global access is a run of 16 lanes over 16 adjacent lines = 128 bytes, or of 32 lanes along a row):
+//   column side:  line = t mod 16, u (or jj) = t div 16        rows as input:  line = t div 32, u = t mod 32
+// Exchange layout: slot(line, p', u) = u * 512 + p' * 16 + ((line + u) mod 16), p' = p mod 32.  Writers (fixed line-or-u, 16 lanes
+// over the other) hit 16 different 8-byte slots mod 16, readers (32 lanes = 16 lines x 2 adjacent p') 32 different ones mod 32:
+// no LDS bank conflicts on either side for either input map.
+#pragma once
+#include "kern_xcd_real.hpp"
+
+namespace mi355 {
+
+#ifndef MI355_RT_NT_OUT
+#define MI355_RT_NT_OUT 0   /* same-box A/B (profiles/r03_regtile_ab.log): temporal output stores r2c 2^22 272 vs 253 G real points/s (its rows start on odd 8-byte
+                               offsets: out pitch N/2 + 1, so neighbouring tiles' partial lines have to meet in the L2), c2c 2^22 171 vs 167 */
+#endif
+#ifndef MI355_RT_ONLY_PHASE
+#define MI355_RT_ONLY_PHASE 0   /* timing-only builds: 1 = phase A alone, 2 = phase B alone (results wrong by construction) */
+#endif
+#ifndef MI355_RT_NT_IN
+#define MI355_RT_NT_IN MI355_XCD_NT
+#endif
+constexpr bool RT_NT_OUT = MI355_RT_NT_OUT != 0, RT_NT_IN = MI355_RT_NT_IN != 0;   // nontemporal output stores / input loads of the register-tile kernels
+
+struct RtCfg {
+  static constexpr int N = 2048, T = 16, THREADS = 512;
+  static constexpr int HALF_ELEMS = T * 32 * 32;   // one half of the exchange
+  static constexpr int TW2_ELEMS = 31 * 64;        // stage-2 roots, rows q2 = 1..31, j2 = 0..63 fastest
+};
+
+// e^{-2 pi i m/64}, m = 0..31 (cos / sin of 2 pi m/64 rounded from an 80-bit evaluation)
+struct Root64 {
+  static constexpr double c[32] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599764, 0.3826834323650898, 0.2902846772544624, 0.19509032201612828, 0.0980171403295606, 0.0, -0.0980171403295606, -0.19509032201612828, -0.2902846772544624, -0.3826834323650898, -0.47139673682599764, -0.5555702330196022, -0.6343932841636455, -0.7071067811865476, -0.773010453362737, -0.8314696123025452, -0.881921264348355, -0.9238795325112867, -0.9569403357322088, -0.9807852804032304, -0.9951847266721969};
+  static constexpr double s[32] = {0.0, 0.0980171403295606, 0.19509032201612828, 0.2902846772544624, 0.3826834323650898, 0.47139673682599764, 0.5555702330196022, 0.6343932841636455, 0.7071067811865476, 0.773010453362737, 0.8314696123025452, 0.881921264348355, 0.9238795325112867, 0.9569403357322088, 0.9807852804032304, 0.9951847266721969, 1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355, 0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196022, 0.47139673682599764, 0.3826834323650898, 0.2902846772544624, 0.19509032201612828, 0.0980171403295606};
+};
+
+// 64-point DFT of v[m], m = 0..63, in registers: output p = 2 q lands in v[q], p = 2 q + 1 in v[32 + q].
+MI_DEV void rt_dft64(cf (&v)[64], cf (&v0)[32], cf (&v1)[32]) {
+#pragma unroll
+  for (int m = 0; m < 32; ++m) {
+    const cf a = v[m] + v[m + 32], b = v[m] - v[m + 32];
+    v0[m] = a;
+    if (m == 0) v1[m] = b;
+    else if (m == 16) v1[m] = mul_neg_i(b);
+    else { cf w; w.x = (float)Root64::c[m]; w.y = (float)(-Root64::s[m]); v1[m] = cmul(b, w); }
+  }
+  fft_radix<32>(v0);
+  fft_radix<32>(v1);
+}
+
+MI_DEV int rt_slot(int line, int pl, int u) { return u * 512 + pl * 16 + ((line + u) & 15); }
+
+// The exchange.  Producer side: this thread's (line, u) and its 64 outputs F[2q] = v0[q], F[2q+1] = v1[q].  Consumer side: this
+// thread's line `rl` and its two consumers, p' = pl0 in the first half (j2 = pl0) and p' = pl1 in the second (j2 = 32 + pl1).
+// rt_exchange_first leaves consumer 0's inputs q2 = 0..31 in w0 and the SECOND half in LDS, so the caller can finish consumer 0
+// (stage 2 + stores: 32 live values instead of 64) before rt_exchange_second picks up consumer 1's inputs; the caller ends the
+// tile with a workgroup barrier (the next tile's first half overwrites the LDS).
+MI_DEV void rt_exchange_first(const cf (&v0)[32], const cf (&v1)[32], cf (&w0)[32], cf* xb, int line, int u, int rl, int pl0) {
+  const int wb = u * 512 + ((line + u) & 15);
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[qq]; xb[wb + (2 * qq + 1) * 16] = v1[qq]; }
+  __syncthreads();
+#pragma unroll
+  for (int uu = 0; uu < 32; ++uu) w0[uu] = xb[uu * 512 + pl0 * 16 + ((rl + uu) & 15)];
+  __syncthreads();
+#pragma unroll
+  for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[16 + qq]; xb[wb + (2 * qq + 1) * 16] = v1[16 + qq]; }
+  __syncthreads();
+  MI_SCHED_FENCE();
+}
+MI_DEV void rt_exchange_second(cf (&w1)[32], const cf* xb, int rl, int pl1) {
+  MI_SCHED_FENCE();
+#pragma unroll
+  for (int uu = 0; uu < 32; ++uu) w1[uu] = xb[uu * 512 + pl1 * 16 + ((rl + uu) & 15)];
+}
+
+// stage 2 of consumer j2: roots e^{-2 pi i q2 j2/2048} from the LDS table, radix 32; output q is element j2 + 64 q of the line
+#ifndef MI355_RT_TW_FENCE
+#define MI355_RT_TW_FENCE 0
+#endif
+MI_DEV void rt_stage2(cf (&w)[32], const cf* tw2, int j2) {
+#pragma unroll
+  for (int q = 1; q < 32; ++q) {
+    w[q] = cmul(w[q], tw2[(q - 1) * 64 + j2]);
+#if MI355_RT_TW_FENCE
+    if (q % MI355_RT_TW_FENCE == 0) MI_SCHED_FENCE();   // keeps the scheduler from requesting all 31 roots at once (62 registers)
+#endif
+  }
+  fft_radix<32>(w);
+}
+
+// four-step roots e^{-2 pi i k1 n2/N} on the 64 inputs n2 = u + 32 m of row k1: exact lookups every 8th m, a recurrence between
+// (kern_xcd.hpp fourstep_apply_chain, for the register tile's input map)
+MI_DEV void rt_fourstep(cf (&v)[64], const XcdFusedArgs& a, unsigned k1, int u) {
+  const auto root = [&](unsigned m) { return cmul(a.tw_hi[m >> a.fs_shift], a.tw_lo[m & a.fs_lo_mask]); };
+  const cf step = root(k1 * 32u);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    cf w = root(k1 * (unsigned)(u + 256 * g));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[8 * g + j] = cmul(v[8 * g + j], w);
+      if (j < 7) w = cmul(w, step);
+    }
+  }
+}
+
+// ---- one tile of a pass ------------------------------------------------------------------------------------------------------
+// Every pass is a load half (64 values per thread into v) and a finish half (64-point DFTs, exchange, stage 2, stores).  The
+// finish half calls `next(v)` as soon as the first exchange half has left the registers that held v: with MI355_RT_PREFETCH the
+// kernels issue the NEXT tile's loads there, so that they are in flight while this tile's second stage computes and stores.
+#ifndef MI355_RT_PREFETCH
+#define MI355_RT_PREFETCH 0      /* number of the 64 loads per thread that are requested one tile ahead (0, 16, 32, 48, 64) */
+#endif
+constexpr int RT_PF = MI355_RT_PREFETCH;
+constexpr bool RT_PREFETCH = RT_PF != 0;
+
+// Column pass (four-step pass A of a [2048][S] matrix): 16 adjacent columns starting at c0, x -> W in place-layout.
+template <bool SWAP_IN, bool NT_IN, int M0 = 0, int M1 = 64>
+MI_DEV void rt_load_cols(cf (&v)[64], const cf* in, unsigned S, unsigned c0, int t) {
+  const int line = t & 15, u = t >> 4;
+  const cf* p = in + c0;
+  const unsigned voff = (unsigned)u * S + (unsigned)line;
+#pragma unroll
+  for (int m = M0; m < M1; ++m) v[m] = cswap_if<SWAP_IN>(ld_stream<NT_IN>(p + (unsigned)(32 * m) * S + voff));
+}
+template <class Next>
+MI_DEV void rt_finish_cols(cf (&v)[64], cf* W, unsigned S, unsigned c0, int t, cf* xb, const cf* tw2, Next&& next) {
+  const int line = t & 15, u = t >> 4;
+  cf v0[32], v1[32], w[32];
+  rt_dft64(v, v0, v1);
+  rt_exchange_first(v0, v1, w, xb, line, u, line, u);        // consumers j2 = u and u + 32 of the same column
+  next(v);
+  cf* po = W + c0;
+  rt_stage2(w, tw2, u);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) po[(unsigned)(u + 64 * q) * S + (unsigned)line] = w[q];
+  rt_exchange_second(w, xb, line, u);
+  rt_stage2(w, tw2, u + 32);
+#pragma unroll
+  for (int q = 0; q < 32; ++q) po[(unsigned)(u + 32 + 64 * q) * S + (unsigned)line] = w[q];
+  __syncthreads();
+}
+
+// Row pass (four-step pass B): 16 adjacent rows k1 = r0 .. r0+15 of W[N1][2048], roots on load, transposed store out[k1 + N1 k2].
+template <int M0 = 0, int M1 = 64>
+MI_DEV void rt_load_rows(cf (&v)[64], const cf* W, unsigned r0, int t) {
+  const int line = t >> 5, u = t & 31;
+  const cf* p = W + (size_t)r0 * RtCfg::N;
+  const unsigned voff = (unsigned)line * RtCfg::N + (unsigned)u;
+#pragma unroll
+  for (int m = M0; m < M1; ++m) v[m] = p[(unsigned)(32 * m) + voff];
+}
+template <bool SWAP_OUT, bool NT_OUT, class Next>
+MI_DEV void rt_finish_rows(cf (&v)[64], cf* out, const XcdFusedArgs& f, unsigned N1, unsigned r0, float scale, int t, cf* xb, const cf* tw2, Next&& next) {
+  const int line = t >> 5, u = t & 31;
+  cf v0[32], v1[32], w[32];
+  rt_fourstep(v, f, r0 + (unsigned)line, u);
+  rt_dft64(v, v0, v1);
+  const int rl = t & 15, jj = t >> 4;
+  rt_exchange_first(v0, v1, w, xb, line, u, rl, jj);
+  next(v);
+  cf* po = out + r0;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (c == 1) rt_exchange_second(w, xb, rl, jj);
+    rt_stage2(w, tw2, jj + 32 * c);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      cf r = w[q];
+      if (scale != 1.0f) r = r * scale;
+      st_stream<NT_OUT>(po + (unsigned)(jj + 32 * c + 64 * q) * N1 + (unsigned)rl, cswap_if<SWAP_OUT>(r));
+    }
+  }
+  __syncthreads();
+}
+
+// ---- the fused kernel: kern_xcd.hpp's group / barrier machinery around register-tile passes ---------------------------------
+// N = N1 * 2048.  N1 = 2048: both passes on register tiles.  N1 = 1024: pass A is the LDS-resident PASS_A configuration CA of
+// kern_lines.hpp (16 x 1024 tiles fit the LDS), pass B the register tile.
+template <int N1_, bool INV> struct XcdRtCfg {
+  static constexpr int N1 = N1_, N2 = RtCfg::N, THREADS = RtCfg::THREADS;
+  static constexpr bool A_RT = N1 == RtCfg::N;
+  using CA = LineCfg<A_RT ? 1024 : N1, 32, (A_RT ? 1024 : N1) / 32, 1, 16, true, true, INV, false, TWID_NONE>;
+  static_assert(A_RT || CA::THREADS == THREADS, "both passes run in the same workgroup");
+  static constexpr int DATA_A = A_RT ? 0 : CA::DATA_ELEMS, TW_A = A_RT ? 0 : CA::TW_ELEMS;
+  static constexpr int DATA = DATA_A > RtCfg::HALF_ELEMS ? DATA_A : RtCfg::HALF_ELEMS;
+  static constexpr int LDS_BYTES = (DATA + TW_A + RtCfg::TW2_ELEMS) * 8 + 64;
+  static_assert(LDS_BYTES <= 160 * 1024, "does not fit LDS");
+};
+
+template <int N1_, bool INV>
+__global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_kernel(const XcdFusedArgs f) {
+  using X = XcdRtCfg<N1_, INV>;
+  using CA = typename X::CA;
+  MI_SMEM_DECL(smem);
+  cf* lds = reinterpret_cast<cf*>(smem);
+  cf* tw_a = lds + X::DATA;
+  cf* tw2 = tw_a + X::TW_A;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + RtCfg::TW2_ELEMS);
+  const int t = threadIdx.x;
+  if constexpr (!X::A_RT) { for (int i = t; i < X::TW_A; i += X::THREADS) tw_a[i] = f.tw_a[i]; }
+  for (int i = t; i < RtCfg::TW2_ELEMS; i += X::THREADS) tw2[i] = f.tw_b[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+
+  constexpr unsigned N1 = X::N1, N2 = X::N2;
+  LineArgs aa{};
+  aa.tw = f.tw_a; aa.num_tiles = N2 / 16; aa.num_lines = N2;
+  aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)f.N;
+    const cf* const x = f.in + tr * f.in_pitch;
+    // ---- phase A: column FFTs of length N1 over 16-column tiles ----
+    if constexpr (MI355_RT_ONLY_PHASE == 2) {
+    } else if constexpr (X::A_RT) {
+      cf v[64];
+      if constexpr (RT_PREFETCH) { if (rank < N2 / 16) rt_load_cols<INV, RT_NT_IN, 0, RT_PF>(v, x, N2, rank * 16u, t); }
+      for (unsigned tile = rank; tile < N2 / 16; tile += gsize) {
+        const unsigned nx = tile + gsize;
+        if constexpr (RT_PF < 64) rt_load_cols<INV, RT_NT_IN, RT_PF, 64>(v, x, N2, tile * 16u, t);
+        rt_finish_cols(v, W, N2, tile * 16u, t, lds, tw2, [&](cf (&vv)[64]) { if (RT_PREFETCH && nx < N2 / 16) rt_load_cols<INV, RT_NT_IN, 0, RT_PF>(vv, x, N2, nx * 16u, t); });
+      }
+    } else {
+      for (unsigned tile = rank; tile < N2 / 16; tile += gsize) {
+        aa.in = x; aa.out = W;
+        cf v[CA::E];
+        stage_read<CA, 0, RT_NT_IN>(v, aa, tile, t, lds);
+        stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
+        __syncthreads();
+        stage_read<CA, 1>(v, aa, tile, t, lds);
+        __syncthreads();
+        stage_compute_write<CA, 1>(v, aa, tile, t, lds, tw_a, nullptr);
+        __syncthreads();
+      }
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B: four-step roots on load, row FFTs of length 2048, transposed store ----
+    cf* const y = f.out + tr * f.out_pitch;
+    if constexpr (MI355_RT_ONLY_PHASE != 1) {
+      cf v[64];
+      if constexpr (RT_PREFETCH) { if (rank < N1 / 16) rt_load_rows<0, RT_PF>(v, W, rank * 16u, t); }
+      for (unsigned tile = rank; tile < N1 / 16; tile += gsize) {
+        const unsigned nx = tile + gsize;
+        if constexpr (RT_PF < 64) rt_load_rows<RT_PF, 64>(v, W, tile * 16u, t);
+        rt_finish_rows<INV, RT_NT_OUT>(v, y, f, N1, tile * 16u, f.scale, t, lds, tw2, [&](cf (&vv)[64]) { if (RT_PREFETCH && nx < N1 / 16) rt_load_rows<0, RT_PF>(vv, W, nx * 16u, t); });
+      }
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
+
+// ---- r2c: the real four-step of kern_xcd_real.hpp on register tiles, N = 2048 x 2048 real points (config 5's line) ------------
+// phase A  16 complex columns (= 32 real columns) per tile; the stage-2 consumers of a thread are j2 = jj and its MIRROR 64 - jj
+//          (jj = 0: consumers 0 and 32, which mirror onto themselves), so that Z[k1] and Z[N1 - k1] of a column meet in one
+//          thread's registers and the two real columns' spectra are separated there (kern_xcd_real.hpp: Y[k1][2c] = (Z[k1] +
+//          conj Z[N1-k1])/2, Y[k1][2c+1] = (Z[k1] - conj Z[N1-k1])/(2i)); rows k1 = 0..N1/2 leave as 16-byte stores.
+// phase B  rows 0..N1/2 of W: four-step roots, row FFT, bins k = k1 + N1 k2 <= N/2 stored directly, the others conjugated at
+//          N - k (rows 0 and N1/2 contribute their first half only, the Nyquist bin stays unconjugated).
+MI_DEV void rt_separate_store(cf* wt, unsigned k1, unsigned N2, cf a, cf b) {
+  cf4 o;
+  o.x = 0.5f * (a.x + b.x); o.y = 0.5f * (a.y - b.y);        // even real column
+  o.z = 0.5f * (a.y + b.y); o.w = 0.5f * (b.x - a.x);        // odd real column: -i/2 * (a - conj b)
+  *reinterpret_cast<cf4*>(wt + (size_t)k1 * N2) = o;
+}
+
+template <int N1_>     // (a template so that only the translation unit of its instance carries the device code)
+__global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const XcdFusedArgs f) {
+  static_assert(N1_ == 2048, "2048 x 2048");
+  MI_SMEM_DECL(smem);
+  cf* xb = reinterpret_cast<cf*>(smem);
+  cf* tw2 = xb + RtCfg::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + RtCfg::TW2_ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < RtCfg::TW2_ELEMS; i += RtCfg::THREADS) tw2[i] = f.tw_b[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+
+  constexpr unsigned N1 = 2048, N2 = 2048, ROWS = N1 / 2 + 1, NREAL = N1 * N2;
+  constexpr size_t wsize = (size_t)ROWS * N2;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * wsize;
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * wsize;
+    const cf* const x = f.in + tr * f.in_pitch;
+    // ---- phase A ----
+    for (unsigned tile = rank; tile < (MI355_RT_ONLY_PHASE == 2 ? 0u : (N2 / 2) / 16); tile += gsize) {
+      const int line = t & 15, jj = t >> 4;
+      cf v[64], v0[32], v1[32];
+      {
+        const cf* p = x + tile * 16u;
+        const unsigned voff = (unsigned)jj * (N2 / 2) + (unsigned)line;
+#pragma unroll
+        for (int m = 0; m < 64; ++m) v[m] = ld_stream<RT_NT_IN>(p + (unsigned)(32 * m) * (N2 / 2) + voff);
+      }
+      rt_dft64(v, v0, v1);
+      cf wa[32], wb[32];
+      const int plb = (32 - jj) & 31;
+      rt_exchange_first(v0, v1, wa, xb, line, jj, line, jj);
+      rt_stage2(wa, tw2, jj);
+      rt_exchange_second(wb, xb, line, plb);
+      rt_stage2(wb, tw2, 32 + plb);
+      cf* const wt = W + tile * 32u + 2u * (unsigned)line;
+      if (jj != 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rt_separate_store(wt, (unsigned)(jj + 64 * q), N2, wa[q], wb[31 - q]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rt_separate_store(wt, (unsigned)(64 - jj + 64 * q), N2, wb[q], wa[31 - q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q <= 16; ++q) rt_separate_store(wt, (unsigned)(64 * q), N2, wa[q], wa[(32 - q) & 31]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rt_separate_store(wt, (unsigned)(32 + 64 * q), N2, wb[q], wb[31 - q]);
+      }
+      __syncthreads();
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B ----
+    cf* const po = f.out + tr * f.out_pitch;
+    for (unsigned tile = rank; tile < (MI355_RT_ONLY_PHASE == 1 ? 0u : (ROWS + 15) / 16); tile += gsize) {
+      cf v[64], v0[32], v1[32];
+      const unsigned r0 = tile * 16u;
+      const int line = t >> 5, u = t & 31;
+      {
+        const unsigned row = r0 + (unsigned)line < ROWS ? r0 + (unsigned)line : ROWS - 1;   // padding rows of the last tile re-read its live row
+        const cf* p = W + (size_t)row * N2 + u;
+#pragma unroll
+        for (int m = 0; m < 64; ++m) v[m] = p[32 * m];
+        rt_fourstep(v, f, row, u);
+      }
+      rt_dft64(v, v0, v1);
+      cf w[32];
+      const int rl = t & 15, jj = t >> 4;
+      const unsigned k1 = r0 + (unsigned)rl;
+      const bool live = k1 < ROWS, edge = k1 == 0 || k1 == N1 / 2;
+      rt_exchange_first(v0, v1, w, xb, line, u, rl, jj);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int j2 = jj + 32 * c;
+        if (c == 1) rt_exchange_second(w, xb, rl, jj);
+        rt_stage2(w, tw2, j2);
+        if (f.scale != 1.0f) {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) w[q] = w[q] * f.scale;
+        }
+        const unsigned kb = k1 + N1 * (unsigned)j2;                     // k = k1 + N1 k2, k2 = j2 + 64 q
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) st_stream<RT_NT_OUT>(po + (kb + (unsigned)(64 * q) * N1), w[q]);
+        }
+        if (live && !edge) {                                            // k > N/2: conjugated at N - k
+#pragma unroll
+          for (int q = 16; q < 32; ++q) { cf mm; mm.x = w[q].x; mm.y = -w[q].y; st_stream<RT_NT_OUT>(po + (NREAL - kb - (unsigned)(64 * q) * N1), mm); }
+        }
+        if (c == 0 && k1 == 0 && jj == 0) st_stream<RT_NT_OUT>(po + NREAL / 2, w[16]);   // k = N/2 (k1 = 0, k2 = N2/2): its own mirror, unconjugated
+      }
+      __syncthreads();
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
+struct XcdRtR2cCfg {
+  static constexpr int THREADS = RtCfg::THREADS, LDS_BYTES = (RtCfg::HALF_ELEMS + RtCfg::TW2_ELEMS) * 8 + 64;
+};
+
+}  // namespace mi355

@@ -87,6 +87,7 @@ const std::vector<ConvKernelMeta>& conv_kernel_registry() {
   return reg;
 }
 
+#define MI_RT_COMMA(n) n,
 const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
   static const std::vector<XcdKernelMeta> reg = [] {
     std::vector<XcdKernelMeta> r;
@@ -95,7 +96,7 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
   {                                                                                                       \
     const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, INV, false, 0);                \
     const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, (REAL) != 3, false, INV, 0);        \
-    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, INV, ma.threads, 0, REAL};          \
+    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, INV, ma.threads, 0, REAL, 0};       \
     const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
     const bool shared = N1 == N2 && A0 == B0 && A1 == B1 && A2 == B2;                                     \
     m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + (shared ? 0 : mb.tw_elems)) * 8 + 64;              \
@@ -118,6 +119,16 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     MI355_XCD_2D_KERNEL_LIST(X)
 #undef X
 #undef XCD_META
+    // register-tile instances (kern_regtile.hpp XcdRtCfg): 512 threads; LDS = max(pass A's LDS tile, one exchange half) + tables
+    for (int n1 : {MI355_XCD_RT_KERNEL_LIST(MI_RT_COMMA)}) for (int inv = 0; inv < 2; ++inv) {
+      const bool a_rt = n1 == 2048;
+      const LineKernelMeta ma = make_meta(0, a_rt ? 1024 : n1, 32, (a_rt ? 1024 : n1) / 32, 1, 16, true, true, inv != 0, false, 0);
+      XcdKernelMeta m{id++, n1, 2048, {32, a_rt ? 64 : n1 / 32, 1}, {64, 32, 1}, 16, 16, inv != 0, 512, 0, 0, 1};
+      const int data_a = a_rt ? 0 : ma.lds_bytes - ma.tw_elems * 8, tw_a = a_rt ? 0 : ma.tw_elems * 8;
+      m.lds_bytes = std::max(data_a, 16 * 32 * 32 * 8) + tw_a + 31 * 64 * 8 + 64;
+      r.push_back(m);
+    }
+    { XcdKernelMeta m{id++, 2048, 2048, {64, 32, 1}, {64, 32, 1}, 16, 16, false, 512, (16 * 32 * 32 + 31 * 64) * 8 + 64, 1, 1}; r.push_back(m); }   // r2c 2048 x 2048 (fft_xcd_rt_r2c_kernel)
     return r;
   }();
   return reg;
@@ -150,6 +161,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_SPLIT")) { const int v = std::atoi(s); if (v >= 0 && v <= 32) o.xcd_split = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_2D")) o.xcd_2d = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_RT")) o.xcd_rt = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
@@ -246,6 +258,12 @@ struct Builder {
   unsigned oneshot_grid(int64_t items) const { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, MAX_BLOCKS)); }
   Step& push(StepKind k) { ir.steps.emplace_back(); ir.steps.back().kind = k; return ir.steps.back(); }
 
+  // stage-2 roots of the register-tile passes (kern_regtile.hpp): e^{-2 pi i q2 j2/2048}, rows q2 = 1..31, j2 = 0..63 fastest
+  PtrRef regtile_table() {
+    std::vector<float2h> t((size_t)31 * 64);
+    for (int q = 1; q < 32; ++q) for (int j = 0; j < 64; ++j) t[(size_t)(q - 1) * 64 + j] = root_of_unity((int64_t)q * j, 2048);
+    return add_table(t);
+  }
   // stage tables of a line kernel: stage 1 [R1-1][R0] roots of order R0*R1, stage 2 [R2-1][R0*R1] of order N
   PtrRef line_tables(const LineKernelMeta& m) {
     std::vector<float2h> t;
@@ -342,10 +360,11 @@ struct Builder {
     const int lgf = lg2(N);
     const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
     const XcdKernelMeta* xm = nullptr;
-    for (const auto& m : xcd_kernel_registry()) if (m.real == (c2r ? 2 : 1) && m.N1 == F1 && m.N2 == F2) xm = &m;
+    for (const auto& m : xcd_kernel_registry())
+      if (m.real == (c2r ? 2 : 1) && m.N1 == F1 && m.N2 == F2 && (!m.rt || (opt.xcd_rt && opt.xcd_shared))) xm = &m;
     if (!xm || (N <= 8192 && opt.xcd_fused != 2)) return false;
-    const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
-    const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
+    const LineKernelMeta ma = make_meta(0, xm->rt ? 1024 : xm->N1, xm->rt ? 32 : xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+    const LineKernelMeta mb = make_meta(0, xm->rt ? 1024 : xm->N2, xm->rt ? 32 : xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
     const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
     // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
     const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / (c2r ? 1 : 2) && opt.xcd_fused != 2;
@@ -367,7 +386,7 @@ struct Builder {
     std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
     for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
-    const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
+    const PtrRef tb = xm->rt ? regtile_table() : line_tables(mb), ta = xm->rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
     if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
@@ -378,7 +397,7 @@ struct Builder {
     st.f[0] = scale;
     if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;   // as emit_axis: two co-resident workgroups per CU
     st.grid = (unsigned)grid;
-    ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : xm->rt ? "xcd-r2c-rt[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
     return true;
   }
 
@@ -629,11 +648,13 @@ struct Builder {
       const int lgf = lg2(N);
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
-      for (const auto& m : xcd_kernel_registry()) if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse) xm = &m;
+      for (const auto& m : xcd_kernel_registry())
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || (opt.xcd_rt && opt.xcd_shared))) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
-        const LineKernelMeta ma = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
-        const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
+        const bool a_rt = xm->rt && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
+        const LineKernelMeta ma = make_meta(0, a_rt ? 1024 : xm->N1, xm->ra[0], a_rt ? 32 : xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+        const LineKernelMeta mb = make_meta(0, xm->rt ? 1024 : xm->N2, xm->rt ? 32 : xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
         // transforms of at most 1 MiB: every workgroup walks whole transforms alone ("solo": no registration, no cross-
         // workgroup barrier, so no co-residency requirement and as many workgroups per CU as fit); larger ones are shared by
         // the groups of an XCD
@@ -655,7 +676,7 @@ struct Builder {
         std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
         for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
         for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
-        const PtrRef ta = line_tables(ma), tb = line_tables(mb), tlo = add_table(lo), thi = add_table(hi);
+        const PtrRef tb = xm->rt ? regtile_table() : line_tables(mb), ta = a_rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
         if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
@@ -666,7 +687,7 @@ struct Builder {
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
         if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;
         st.grid = (unsigned)grid;
-        ir.route += std::string(solo ? "xcd-solo[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }
