@@ -607,6 +607,25 @@ def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-rt {label} {direction}")
 
 
+@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (3, 1, 2, 1)])
+def test_c2c_xcd_two_workgroups_per_cu(oracle, monkeypatch, cus, xcds, split, slots):
+    """N = 2^20 on register tiles with the exchange in two 64 KB halves (kern_regtile.hpp fft_xcd_hx_kernel): 72 KB of LDS and 128
+    VGPRs per workgroup, two workgroups per CU (grid = 2 x CUs)"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_HX", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
+    monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
+    monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
+    n, batch = 1 << 20, 5
+    x = oracle.random_complex_batch(n, batch, 0x2820 + cus).reshape(-1)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm)
+        got, route, launches = emu.run_plan(desc, x, x.size)
+        assert route.startswith("xcd-fused-2wg[N=1024x1024]") and launches == 2, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-2wg {direction}")
+
+
 @pytest.mark.parametrize("lg,label,cus", [(15, "128x256", 3), (16, "256x256", 2), (17, "256x512", 5)])
 def test_c2c_xcd_solo_sizes(oracle, monkeypatch, lg, label, cus):
     """transforms of at most 1 MiB: one workgroup walks a whole transform (both passes, its own workspace slot, no cross-

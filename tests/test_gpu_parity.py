@@ -145,6 +145,18 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
+def test_c2c_two_workgroups_per_cu(fft, dev, oracle, monkeypatch):
+    """N = 2^20 on the opt-in register-tile kernel with two workgroups per CU (kern_regtile.hpp fft_xcd_hx_kernel; measured slower
+    than the shipped kernel, profiles/r03_headline_2wg_ab.log): 19 transforms over the groups, both directions, against the oracle"""
+    monkeypatch.setenv("MI355FFT_XCD_HX", "1")
+    n, batch = 1 << 20, 19
+    x = oracle.random_complex_batch(n, batch, 0xE520).reshape(-1)
+    for direction in ("forward", "inverse"):
+        got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
+        assert route.startswith("xcd-fused-2wg[N=1024x1024]") and launches == 2, route
+        check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} {direction}")
+
+
 @pytest.mark.parametrize("depth", [4, 2, 1])
 def test_c2c_xcd_resident(fft, dev, oracle, monkeypatch, depth):
     """N = 2^20 on the XCD-resident kernel (kern_xcd_res.hpp): the transform is handed between the 32 workgroups of an XCD through

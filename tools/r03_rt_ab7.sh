@@ -1,0 +1,5 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+L=$GRAFT_REPO_ROOT/webgpu-fft_amd
+tools/ab_env.sh "r2c_2p22_b1024" "MI355FFT_XCD_RT=1;MI355FFT_LIB=$L/lib_ealn/libmi355fft.so;MI355FFT_LIB=$L/lib_epb/libmi355fft.so;MI355FFT_LIB=$L/lib_epbaln/libmi355fft.so" 2>&1 | tee gpurun_out/r03_rt_ab7.log

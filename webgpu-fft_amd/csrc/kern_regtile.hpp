@@ -21,12 +21,22 @@
 // no LDS bank conflicts on either side for either input map.
 #pragma once
 #include "kern_xcd_real.hpp"
+#include "kern_xcd_res.hpp"   // sgpr_base(): uniform 64-bit bases stay in SGPRs, lanes add a 32-bit offset
 
 namespace mi355 {
 
 #ifndef MI355_RT_NT_OUT
 #define MI355_RT_NT_OUT 0   /* same-box A/B (profiles/r03_regtile_ab.log): temporal output stores r2c 2^22 272 vs 253 G real points/s (its rows start on odd 8-byte
                                offsets: out pitch N/2 + 1, so neighbouring tiles' partial lines have to meet in the L2), c2c 2^22 171 vs 167 */
+#endif
+#ifndef MI355_RT_EXP_SKIP_LAST
+#define MI355_RT_EXP_SKIP_LAST 0   /* timing-only: r2c phase B without its 65th row tile (row N1/2 alone) */
+#endif
+#ifndef MI355_RT_EXP_ALIGN
+#define MI355_RT_EXP_ALIGN 0       /* timing-only: r2c output rows on a pitch of N/2 (128-byte aligned segments) */
+#endif
+#ifndef MI355_RT_EXP_ASC
+#define MI355_RT_EXP_ASC 0         /* timing-only: the mirrored stores of r2c phase B in ascending lane order (wrong rows) */
 #endif
 #ifndef MI355_RT_ONLY_PHASE
 #define MI355_RT_ONLY_PHASE 0   /* timing-only builds: 1 = phase A alone, 2 = phase B alone (results wrong by construction) */
@@ -93,6 +103,7 @@ MI_DEV void rt_exchange_second(cf (&w1)[32], const cf* xb, int rl, int pl1) {
 #define MI355_RT_TW_FENCE 0
 #endif
 MI_DEV void rt_stage2(cf (&w)[32], const cf* tw2, int j2) {
+  MI_OPAQUE_LANE_INT(j2);   // the 31 roots of a thread are the same for every tile: hoisted out of the tile loop they would pin 62 registers
 #pragma unroll
   for (int q = 1; q < 32; ++q) {
     w[q] = cmul(w[q], tw2[(q - 1) * 64 + j2]);
@@ -339,13 +350,19 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
     xcd_arrive(&f.ctl->bar[gslot][0]);
     if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     // ---- phase B ----
-    cf* const po = f.out + tr * f.out_pitch;
-    for (unsigned tile = rank; tile < (MI355_RT_ONLY_PHASE == 1 ? 0u : (ROWS + 15) / 16); tile += gsize) {
+    cf* const po = f.out + tr * (f.out_pitch - MI355_RT_EXP_ALIGN);
+    // (The packed rows start on odd 8-byte offsets — pitch N/2 + 1 — so every 128-byte run of these stores straddles two cache
+    // lines.  Shifting the row tiles of a transform by its offset so that the direct stores land on whole lines measured no gain,
+    // 275.5 vs 278 G real points/s: profiles/r03_regtile_ab.log; the mirrored stores sit one element further and cannot be aligned
+    // at the same time.  Temporal stores, which let the partial lines of neighbouring tiles meet in the L2, are what helps: +7 %.)
+    constexpr int sh = 0;
+    for (unsigned tile = rank; tile < (MI355_RT_ONLY_PHASE == 1 ? 0u : (ROWS + 15) / 16 - MI355_RT_EXP_SKIP_LAST); tile += gsize) {
       cf v[64], v0[32], v1[32];
-      const unsigned r0 = tile * 16u;
+      const int r0 = (int)(tile * 16u) - sh;
       const int line = t >> 5, u = t & 31;
       {
-        const unsigned row = r0 + (unsigned)line < ROWS ? r0 + (unsigned)line : ROWS - 1;   // padding rows of the last tile re-read its live row
+        const int rr = r0 + line;
+        const unsigned row = rr < 0 ? 0u : (rr < (int)ROWS ? (unsigned)rr : ROWS - 1);   // padding rows re-read a live row
         const cf* p = W + (size_t)row * N2 + u;
 #pragma unroll
         for (int m = 0; m < 64; ++m) v[m] = p[32 * m];
@@ -354,8 +371,9 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
       rt_dft64(v, v0, v1);
       cf w[32];
       const int rl = t & 15, jj = t >> 4;
-      const unsigned k1 = r0 + (unsigned)rl;
-      const bool live = k1 < ROWS, edge = k1 == 0 || k1 == N1 / 2;
+      const int k1s = r0 + rl;
+      const unsigned k1 = (unsigned)k1s;
+      const bool live = k1s >= 0 && k1s < (int)ROWS, edge = k1 == 0 || k1 == N1 / 2;
       rt_exchange_first(v0, v1, w, xb, line, u, rl, jj);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -373,7 +391,7 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
         }
         if (live && !edge) {                                            // k > N/2: conjugated at N - k
 #pragma unroll
-          for (int q = 16; q < 32; ++q) { cf mm; mm.x = w[q].x; mm.y = -w[q].y; st_stream<RT_NT_OUT>(po + (NREAL - kb - (unsigned)(64 * q) * N1), mm); }
+          for (int q = 16; q < 32; ++q) { cf mm; mm.x = w[q].x; mm.y = -w[q].y; st_stream<RT_NT_OUT>(po + (NREAL - MI355_RT_EXP_ALIGN - (MI355_RT_EXP_ASC ? kb + 15u - 2u * (unsigned)rl : kb) - (unsigned)(64 * q) * N1), mm); }
         }
         if (c == 0 && k1 == 0 && jj == 0) st_stream<RT_NT_OUT>(po + NREAL / 2, w[16]);   // k = N/2 (k1 = 0, k2 = N2/2): its own mirror, unconjugated
       }
@@ -388,5 +406,136 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
 struct XcdRtR2cCfg {
   static constexpr int THREADS = RtCfg::THREADS, LDS_BYTES = (RtCfg::HALF_ELEMS + RtCfg::TW2_ELEMS) * 8 + 64;
 };
+
+// ---- N = 1024 x 1024 (the headline's size) with TWO workgroups per CU -----------------------------------------------------------
+// The LDS-resident fused kernel (kern_xcd.hpp) holds a 16 x 1024 tile in 128 KB of LDS: one 512-thread workgroup per CU, whose
+// load, compute and store phases cannot overlap (the arithmetic costs it 9 %: profiles/r02_no_math_bound.log).  Here the tile
+// lives in registers (32 values per thread) and its one exchange goes through LDS in two halves of 64 KB — outputs p < 16 of every
+// radix-32 butterfly first (consumers j2 < 16: the threads of waves 0..3), then p >= 16 (waves 4..7) — so a workgroup needs 72 KB
+// of LDS and at most 128 VGPRs, and two of them share a CU: while one computes, the other streams.
+#ifndef MI355_HX_WAVES
+#define MI355_HX_WAVES 4
+#endif
+struct HxCfg {
+  static constexpr int N = 1024, T = 16, THREADS = 512;
+  static constexpr int HALF_ELEMS = T * 32 * 16;
+  static constexpr int TW1_ELEMS = 31 * 32;        // stage-1 roots e^{-2 pi i q k/1024}, rows q = 1..31, k = 0..31 fastest (a LineCfg<1024,32,32> table)
+  static constexpr int LDS_BYTES = (HALF_ELEMS + TW1_ELEMS) * 8 + 64;
+};
+
+// producer (line, u): outputs v[p] of its radix-32 butterfly; consumer (rl, jj): inputs q2 = 0..31 of butterfly j2 = jj.
+// `first` (wave-uniform, in an SGPR) says in which half this wave's consumers are served.  The two cases are separate straight-line
+// paths with the same barrier sequence: one path with conditionally executed reads leaves w partly undefined for the optimiser,
+// which then keeps 64 registers alive across the whole tile loop.
+MI_DEV void hx_exchange(const cf (&v)[32], cf (&w)[32], cf* xb, int line, int u, int rl, int jj, bool first) {
+  const int wb = u * 256 + ((line + u) & 15);
+  const int rb = (jj & 15) * 16;
+  if (first) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[wb + q * 16] = v[q];
+    __syncthreads();
+#pragma unroll
+    for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 256 + rb + ((rl + uu) & 15)];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[wb + q * 16] = v[16 + q];
+    __syncthreads();
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[wb + q * 16] = v[q];
+    __syncthreads();
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xb[wb + q * 16] = v[16 + q];
+    __syncthreads();
+#pragma unroll
+    for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 256 + rb + ((rl + uu) & 15)];
+    __syncthreads();
+  }
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(HxCfg::THREADS, MI355_HX_WAVES) fft_xcd_hx_kernel(const XcdFusedArgs f) {
+  MI_SMEM_DECL(smem);
+  cf* xb = reinterpret_cast<cf*>(smem);
+  cf* tw1 = xb + HxCfg::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + HxCfg::TW1_ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < HxCfg::TW1_ELEMS; i += HxCfg::THREADS) tw1[i] = f.tw_a[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+  constexpr unsigned N1 = 1024, N2 = 1024, NT = 64;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
+  const int cl = t & 15, cu = t >> 4;       // column-side map (loads of pass A, stores of both passes)
+  const int rl_ = t >> 5, ru = t & 31;      // row-side map (loads of pass B)
+  const bool first = MI_UNIFORM_U32((unsigned)t >> 8) == 0u;   // consumers j2 = t div 16 < 16: waves 0..3
+  const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)f.N;
+    const cf* const x = f.in + tr * f.in_pitch;
+    // ---- phase A: 16 adjacent columns per tile, x -> W in place-layout ----
+    for (unsigned tile = rank; tile < NT; tile += gsize) {
+      cf v[32], w[32];
+      {
+        const cf* p = x + tile * 16u;
+        const unsigned voff = (unsigned)cu * N2 + (unsigned)cl;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = cswap_if<INV>(ld_stream<RT_NT_IN>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
+      }
+      fft_radix<32>(v);
+      hx_exchange(v, w, xb, cl, cu, cl, cu, first);
+      { int ti = cu; MI_OPAQUE_LANE_INT(ti);   // (not loop-invariant for the optimiser: hoisted, the 31 roots would pin 62 registers)
+#pragma unroll
+      for (int q = 1; q < 32; ++q) w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]); }
+      fft_radix<32>(w);
+      cf* po = W + tile * 16u;
+      const unsigned so = (unsigned)cu * N2 + (unsigned)cl;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) *(sgpr_base(po + (unsigned)(32 * q) * N2) + so) = w[q];
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B: 16 adjacent rows per tile, four-step roots on load, transposed store ----
+    cf* const y = f.out + tr * f.out_pitch;
+    for (unsigned tile = rank; tile < NT; tile += gsize) {
+      cf v[32], w[32];
+      {
+        const unsigned k1 = tile * 16u + (unsigned)rl_;
+        const cf* p = W + (size_t)(tile * 16u) * N2;
+        const unsigned lo = (unsigned)rl_ * N2 + (unsigned)ru;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) v[q] = *(sgpr_base(p + 32 * q) + lo);
+        const cf step = root(k1 * 32u);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          cf r = root(k1 * (unsigned)(ru + 256 * g));
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { v[8 * g + j] = cmul(v[8 * g + j], r); if (j < 7) r = cmul(r, step); }
+        }
+      }
+      fft_radix<32>(v);
+      hx_exchange(v, w, xb, rl_, ru, cl, cu, first);
+      { int ti = cu; MI_OPAQUE_LANE_INT(ti);
+#pragma unroll
+      for (int q = 1; q < 32; ++q) w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]); }
+      fft_radix<32>(w);
+      cf* po = y + tile * 16u;
+      const unsigned so = (unsigned)cu * N1 + (unsigned)cl;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        cf r = w[q];
+        if (f.scale != 1.0f) r = r * f.scale;
+        st_stream<XCD_NT>(sgpr_base(po + (unsigned)(32 * q) * N1) + so, cswap_if<INV>(r));
+      }
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
 
 }  // namespace mi355

@@ -129,6 +129,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
       r.push_back(m);
     }
     { XcdKernelMeta m{id++, 2048, 2048, {64, 32, 1}, {64, 32, 1}, 16, 16, false, 512, (16 * 32 * 32 + 31 * 64) * 8 + 64, 1, 1}; r.push_back(m); }   // r2c 2048 x 2048 (fft_xcd_rt_r2c_kernel)
+    for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 with two workgroups per CU (fft_xcd_hx_kernel): rt = 2
+      XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 16, 16, inv != 0, 512, (16 * 32 * 16 + 31 * 32) * 8 + 64, 0, 2}; r.push_back(m);
+    }
     return r;
   }();
   return reg;
@@ -162,6 +165,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_R2C")) o.xcd_r2c = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_2D")) o.xcd_2d = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RT")) o.xcd_rt = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_XCD_HX")) o.xcd_hx = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
@@ -649,12 +653,12 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry())
-        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || (opt.xcd_rt && opt.xcd_shared))) xm = &m;
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx : opt.xcd_rt) && opt.xcd_shared))) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
-        const bool a_rt = xm->rt && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
+        const bool a_rt = xm->rt == 1 && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
         const LineKernelMeta ma = make_meta(0, a_rt ? 1024 : xm->N1, xm->ra[0], a_rt ? 32 : xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
-        const LineKernelMeta mb = make_meta(0, xm->rt ? 1024 : xm->N2, xm->rt ? 32 : xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
+        const LineKernelMeta mb = make_meta(0, xm->rt == 1 ? 1024 : xm->N2, xm->rt == 1 ? 32 : xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
         // transforms of at most 1 MiB: every workgroup walks whole transforms alone ("solo": no registration, no cross-
         // workgroup barrier, so no co-residency requirement and as many workgroups per CU as fit); larger ones are shared by
         // the groups of an XCD
@@ -676,7 +680,7 @@ struct Builder {
         std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
         for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
         for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
-        const PtrRef tb = xm->rt ? regtile_table() : line_tables(mb), ta = a_rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
+        const PtrRef tb = xm->rt == 1 ? regtile_table() : line_tables(mb), ta = a_rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
         if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
@@ -685,9 +689,9 @@ struct Builder {
         st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0; st.i[13] = opt.xcd_spin_limit;
         st.f[0] = scale;
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
-        if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;
+        if (!solo && opt.xcd_fused != 2 && ((xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) || xm->rt == 2)) grid *= 2;
         st.grid = (unsigned)grid;
-        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }

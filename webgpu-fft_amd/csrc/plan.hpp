@@ -86,7 +86,7 @@ const std::vector<MixedCtMeta>& mixedct_registry();
 // registers (128-byte segments where the LDS-resident 8-line tiles above move 64-byte ones); forward and inverse.  Listed AFTER
 // the LDS-resident instances of the same size so that a registry walk finds them last (PlannerOptions::xcd_rt).
 #define MI355_XCD_RT_KERNEL_LIST(X) X(1024) X(2048)
-struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; int rt; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c; rt: register-tile instance
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; int rt; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c; rt: 1 register-tile instance (2048-point sides), 2 the two-workgroups-per-CU 1024 x 1024
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
@@ -159,6 +159,7 @@ struct PlannerOptions {
   int xcd_res_depth = 4;               // exchange channels in flight per XCD (1, 2, 4): 1 MiB of L2-resident buffer each
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_rt = 1;                      // 2048-point sides on register tiles (kern_regtile.hpp) where an instance exists (0: the LDS-resident 8-line tiles / two-pass route)
+  int xcd_hx = 0;                      // N = 2^20: the register-tile kernel with two workgroups per CU (kern_regtile.hpp fft_xcd_hx_kernel) instead of the LDS-resident fused kernel
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int solo_cap_mb = 256;               // solo mode: all workgroups' workspace slots together (MiB) = the Infinity Cache (r02: 2^16 203 vs 189 GPoints/s with 1024; below 256 occupancy collapses)
