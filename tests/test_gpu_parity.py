@@ -499,7 +499,7 @@ def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
 
 
 @pytest.mark.parametrize("fused", [0, 1])
-@pytest.mark.parametrize("lg,batch", [(15, 1200), (16, 600), (17, 300), (18, 70), (19, 37), (20, 35), (21, 19)])
+@pytest.mark.parametrize("lg,batch", [(15, 1200), (16, 600), (17, 300), (18, 70), (19, 37), (20, 35), (21, 19), (22, 18)])
 def test_c2r_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     """long power-of-two c2r on both routes (XCD-fused Hermitian four-step / half-length pre-split + inverse c2c):
     against the oracle's c2r of the oracle's own spectrum, and the round trip back to the signal"""
@@ -512,7 +512,7 @@ def test_c2r_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     x = oracle.random_real_batch(n, batch, 0xE200 + lg).reshape(-1)
     spec = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none", use_pow2=True) for b in range(batch)])
     got, (route, launches) = run_plan(fft, dev, {"type": "c2r", "shape": [n], "batch": batch, "direction": "inverse", "normalize": "backward"}, spec, n * batch)
-    assert route.startswith("xcd-c2r") == bool(fused and lg <= 20), route   # 2^21: half-length route
+    assert route.startswith("xcd-c2r-rt[" if lg == 22 else "xcd-c2r") == bool(fused and lg != 21), route   # 2^21: half-length route; 2^22 (r03): register tiles
     check(oracle, got, x, f"c2r(r2c) 2^{lg} ({route.strip()})", 2e-3, 2e-3)
     want = np.concatenate([oracle.c2r_ref_from_packed(spec[2 * b * p:2 * (b + 1) * p], n, "backward", use_pow2=True) for b in range(3)])
     check(oracle, got[:3 * n], want, f"c2r vs oracle 2^{lg}", 2e-3, 2e-3)

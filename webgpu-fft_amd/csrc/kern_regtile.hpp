@@ -79,16 +79,29 @@ MI_DEV int rt_slot(int line, int pl, int u) { return u * 512 + pl * 16 + ((line 
 // rt_exchange_first leaves consumer 0's inputs q2 = 0..31 in w0 and the SECOND half in LDS, so the caller can finish consumer 0
 // (stage 2 + stores: 32 live values instead of 64) before rt_exchange_second picks up consumer 1's inputs; the caller ends the
 // tile with a workgroup barrier (the next tile's first half overwrites the LDS).
+// PARITY: the halves are the even outputs p = 2q (v0) and the odd ones (v1) instead of p < 32 and p >= 32 — a thread's two
+// consumers are then j2 = 2 pl0 and 2 pl1 + 1 (adjacent lines of the result, which the c2r pass packs into one complex row).
+template <bool PARITY = false>
 MI_DEV void rt_exchange_first(const cf (&v0)[32], const cf (&v1)[32], cf (&w0)[32], cf* xb, int line, int u, int rl, int pl0) {
   const int wb = u * 512 + ((line + u) & 15);
+  if constexpr (PARITY) {
 #pragma unroll
-  for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[qq]; xb[wb + (2 * qq + 1) * 16] = v1[qq]; }
+    for (int q = 0; q < 32; ++q) xb[wb + q * 16] = v0[q];
+  } else {
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[qq]; xb[wb + (2 * qq + 1) * 16] = v1[qq]; }
+  }
   __syncthreads();
 #pragma unroll
   for (int uu = 0; uu < 32; ++uu) w0[uu] = xb[uu * 512 + pl0 * 16 + ((rl + uu) & 15)];
   __syncthreads();
+  if constexpr (PARITY) {
 #pragma unroll
-  for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[16 + qq]; xb[wb + (2 * qq + 1) * 16] = v1[16 + qq]; }
+    for (int q = 0; q < 32; ++q) xb[wb + q * 16] = v1[q];
+  } else {
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) { xb[wb + (2 * qq) * 16] = v0[16 + qq]; xb[wb + (2 * qq + 1) * 16] = v1[16 + qq]; }
+  }
   __syncthreads();
   MI_SCHED_FENCE();
 }
@@ -176,11 +189,11 @@ MI_DEV void rt_load_rows(cf (&v)[64], const cf* W, unsigned r0, int t) {
 #pragma unroll
   for (int m = M0; m < M1; ++m) v[m] = p[(unsigned)(32 * m) + voff];
 }
-template <bool SWAP_OUT, bool NT_OUT, class Next>
+template <bool SWAP_OUT, bool NT_OUT, bool FOURSTEP = true, class Next>
 MI_DEV void rt_finish_rows(cf (&v)[64], cf* out, const XcdFusedArgs& f, unsigned N1, unsigned r0, float scale, int t, cf* xb, const cf* tw2, Next&& next) {
   const int line = t >> 5, u = t & 31;
   cf v0[32], v1[32], w[32];
-  rt_fourstep(v, f, r0 + (unsigned)line, u);
+  if constexpr (FOURSTEP) rt_fourstep(v, f, r0 + (unsigned)line, u);
   rt_dft64(v, v0, v1);
   const int rl = t & 15, jj = t >> 4;
   rt_exchange_first(v0, v1, w, xb, line, u, rl, jj);
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_kernel(const XcdFus
       for (unsigned tile = rank; tile < N1 / 16; tile += gsize) {
         const unsigned nx = tile + gsize;
         if constexpr (RT_PF < 64) rt_load_rows<RT_PF, 64>(v, W, tile * 16u, t);
-        rt_finish_rows<INV, RT_NT_OUT>(v, y, f, N1, tile * 16u, f.scale, t, lds, tw2, [&](cf (&vv)[64]) { if (RT_PREFETCH && nx < N1 / 16) rt_load_rows<0, RT_PF>(vv, W, nx * 16u, t); });
+        rt_finish_rows<INV, RT_NT_OUT, true>(v, y, f, N1, tile * 16u, f.scale, t, lds, tw2, [&](cf (&vv)[64]) { if (RT_PREFETCH && nx < N1 / 16) rt_load_rows<0, RT_PF>(vv, W, nx * 16u, t); });
       }
     }
     if (!two_slots) {
@@ -406,6 +419,96 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
 struct XcdRtR2cCfg {
   static constexpr int THREADS = RtCfg::THREADS, LDS_BYTES = (RtCfg::HALF_ELEMS + RtCfg::TW2_ELEMS) * 8 + 64;
 };
+
+// ---- c2r: the Hermitian four-step of kern_xcd_real.hpp on register tiles, N = 2048 x 2048 real samples -----------------------
+// x = IFFT(X) = FFT(conj X) for real x: a FORWARD four-step over Xt = conj(X_full), input index n1*N2 + n2 (bins), output
+// k1 + N1*k2 (samples).
+// phase A  columns n2 = 0..N2/2 (65 tiles of 16, the last with one live column); a column's upper half is read conjugated from the
+//          stored bins, its lower half is the unconjugated upper half of column N2 - n2 walked backwards.  The exchange halves are
+//          the even and the odd outputs, so a thread ends up with the ADJACENT results k1 = 2i + 64q and 2i + 1 + 64q of its
+//          column: it multiplies them by the four-step roots e^{-2 pi i k1 n2/N} and packs the pair as z = a + i b into row
+//          p = k1/2 of W at n2 — and, because every such row is Hermitian in n2, its extension conj(a) + i conj(b) at N2 - n2.
+//          W = [N1/2][N2] holds full-length packed rows.  (Packing in pass B instead, as kern_xcd_real.hpp does, makes every
+//          thread of pass B fetch two rows through two root chains in register-bounded batches: 175 vs 218 G real samples/s for
+//          the half-length route, profiles/r03_regtile_ab.log.)
+// phase B  a plain length-N2 row FFT of the N1/2 packed rows; real part = sample k1 = 2p, imaginary part = 2p + 1: adjacent in
+//          the output, i.e. the transposed store of the c2c pass B with N1/2 complex rows writes the real line directly.
+template <int N1_>
+__global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_c2r_kernel(const XcdFusedArgs f) {
+  static_assert(N1_ == 2048, "2048 x 2048");
+  MI_SMEM_DECL(smem);
+  cf* xb = reinterpret_cast<cf*>(smem);
+  cf* tw2 = xb + RtCfg::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + RtCfg::TW2_ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < RtCfg::TW2_ELEMS; i += RtCfg::THREADS) tw2[i] = f.tw_b[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+
+  constexpr int N1 = 2048, N2 = 2048, COLS = N2 / 2 + 1;
+  constexpr size_t wsize = (size_t)(N1 / 2) * N2;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * wsize;
+  const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * wsize;
+    const cf* const X = f.in + tr * f.in_pitch;
+    // ---- phase A ----
+    for (unsigned tile = rank; tile < (COLS + 15) / 16; tile += gsize) {
+      const int line = t & 15, i = t >> 4;
+      cf v[64], v0[32], v1[32];
+      const int n2r = (int)(tile * 16u) + line;
+      const int n2 = n2r > N2 / 2 ? N2 / 2 : n2r;                        // padding lines of the last tile re-read its live column
+      {
+        const int up = i * N2 + n2;                                      // n1 = i + 32 m < N1/2: stored bin, conjugated
+        const int lo = n2 ? (N1 - 1 - i) * N2 + (N2 - n2) : (N1 - i) * N2;   // n1 >= N1/2: bin N - n, as stored
+#pragma unroll
+        // (temporal loads: the packed rows start on odd 8-byte offsets — pitch N/2 + 1 — so every 128-byte run straddles two cache
+        // lines whose other parts the neighbouring tiles read; nontemporal: 232 vs 245 G real samples/s, profiles/r03_regtile_ab.log)
+        for (int m = 0; m < 32; ++m) { const cf x = X[up + (32 * m) * N2]; v[m] = cf{x.x, -x.y}; }
+#pragma unroll
+        for (int m = 32; m < 64; ++m) v[m] = X[lo - (32 * m) * N2];
+      }
+      rt_dft64(v, v0, v1);
+      cf wa[32], wb[32];
+      rt_exchange_first<true>(v0, v1, wa, xb, line, i, line, i);
+      rt_stage2(wa, tw2, 2 * i);
+      rt_exchange_second(wb, xb, line, i);
+      rt_stage2(wb, tw2, 2 * i + 1);
+      // roots e^{-2 pi i k1 n2/N}, k1 = 2i (+1) + 64 q: exact lookups every 8th q, the step e^{-2 pi i 64 n2/N} between; pack and store
+      const bool live = n2r <= N2 / 2, mirror = live && n2r >= 1 && n2r < N2 / 2;
+      const cf step = root(64u * (unsigned)n2);
+      cf* const pd = W + (unsigned)i * N2 + (unsigned)n2;
+      cf* const pm = W + (unsigned)i * N2 + (unsigned)(N2 - n2);
+#pragma unroll
+      for (int g = 0; g < 32; g += 8) {
+        cf ra = root((unsigned)(2 * i + 64 * g) * (unsigned)n2), rb = root((unsigned)(2 * i + 1 + 64 * g) * (unsigned)n2);
+#pragma unroll
+        for (int q = g; q < g + 8; ++q) {
+          const cf a = cmul(wa[q], ra), b = cmul(wb[q], rb);
+          if (live) pd[(unsigned)(32 * q) * N2] = cf{a.x - b.y, a.y + b.x};       // a + i b
+          if (mirror) pm[(unsigned)(32 * q) * N2] = cf{a.x + b.y, b.x - a.y};     // conj(a) + i conj(b)
+          ra = cmul(ra, step); rb = cmul(rb, step);
+        }
+      }
+      __syncthreads();
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B ----
+    cf* const y = f.out + tr * f.out_pitch;
+    for (unsigned tile = rank; tile < (N1 / 2) / 16; tile += gsize) {
+      cf v[64];
+      rt_load_rows(v, W, tile * 16u, t);
+      rt_finish_rows<false, RT_NT_OUT, false>(v, y, f, N1 / 2, tile * 16u, f.scale, t, xb, tw2, [](cf (&)[64]) {});
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
 
 // ---- N = 1024 x 1024 (the headline's size) with TWO workgroups per CU -----------------------------------------------------------
 // The LDS-resident fused kernel (kern_xcd.hpp) holds a 16 x 1024 tile in 128 KB of LDS: one 512-thread workgroup per CU, whose

@@ -132,6 +132,7 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 with two workgroups per CU (fft_xcd_hx_kernel): rt = 2
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 16, 16, inv != 0, 512, (16 * 32 * 16 + 31 * 32) * 8 + 64, 0, 2}; r.push_back(m);
     }
+    { XcdKernelMeta m{id++, 2048, 2048, {64, 32, 1}, {64, 32, 1}, 16, 16, false, 512, (16 * 32 * 32 + 31 * 64) * 8 + 64, 2, 1}; r.push_back(m); }   // c2r 2048 x 2048 (fft_xcd_rt_c2r_kernel)
     return r;
   }();
   return reg;
@@ -369,7 +370,7 @@ struct Builder {
     if (!xm || (N <= 8192 && opt.xcd_fused != 2)) return false;
     const LineKernelMeta ma = make_meta(0, xm->rt ? 1024 : xm->N1, xm->rt ? 32 : xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
     const LineKernelMeta mb = make_meta(0, xm->rt ? 1024 : xm->N2, xm->rt ? 32 : xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
-    const int64_t wsize = c2r ? F1 * (F2 / 2 + 16) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding)
+    const int64_t wsize = c2r ? (xm->rt ? (F1 / 2) * F2 : F1 * (F2 / 2 + 16)) : (F1 / 2 + 1) * F2;   // r2c: rows 0..N1/2; c2r: columns 0..N2/2 (+ padding; register tiles: N1/2 packed full rows)
     // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
     const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / (c2r ? 1 : 2) && opt.xcd_fused != 2;
     if (!solo && !opt.xcd_shared) return false;
@@ -401,7 +402,7 @@ struct Builder {
     st.f[0] = scale;
     if (!solo && opt.xcd_fused != 2 && xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;   // as emit_axis: two co-resident workgroups per CU
     st.grid = (unsigned)grid;
-    ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : xm->rt ? "xcd-r2c-rt[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    ir.route += std::string(c2r ? (solo ? "xcd-c2r-solo[N=" : xm->rt ? "xcd-c2r-rt[N=" : "xcd-c2r[N=") : (solo ? "xcd-r2c-solo[N=" : xm->rt ? "xcd-r2c-rt[N=" : "xcd-r2c[N=")) + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
     return true;
   }
 
