@@ -690,6 +690,7 @@ def test_c2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     monkeypatch.setenv("MI355_EMU_CUS", "4")
     monkeypatch.setenv("MI355_EMU_XCDS", "1")
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", "2")
+    monkeypatch.setenv("MI355_EMU_XCD_RT", "0")          # 2^21: the LDS-resident instance (the register-tile one: test_c2c_xcd_regtile)
     n, batch = 1 << lg, 3
     x = oracle.random_complex_batch(n, batch, 0xBEEF + lg).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):

@@ -131,8 +131,17 @@ struct LineCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "tile does not fit LDS");
 };
 
+// SWZ16 (three-stage ROW plans with a 16-point first stage: 2048 = 16*16*8, 4096 = 16*16*16): the padded form makes the 32-lane
+// groups of the consecutive-index ds_read_b64 of stages 1 and 2 hit one bank pair twice (idx + idx/16 repeats mod 32 every 32
+// elements: 17-23 % of the LDS cycles of these shapes were conflict cycles, profiles/r02_lds_bank_conflicts.log).  Rotating the
+// low four index bits by the 16-block number instead keeps every aligned block of 16 a permutation of itself — consecutive
+// indices stay conflict-free — and still spreads the stride-16 writes of stage 0 (fixed q, lanes over u: low bits q + u).
+#ifndef MI355_LDS_SWZ16
+#define MI355_LDS_SWZ16 0
+#endif
 template <class C> MI_DEV int lds_index(int line, int idx) {
   if constexpr (C::IDX_MAJOR) return idx * C::T + line;
+  else if constexpr (MI355_LDS_SWZ16 && !C::IN_COL && !C::OUT_COL && C::NSTAGES == 3 && C::R0 == 16) return line * C::PITCH + ((idx & ~15) | ((idx + (idx >> 4)) & 15));
   else return line * C::PITCH + idx + (idx >> C::PADSH);
 }
 
