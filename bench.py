@@ -169,6 +169,27 @@ def pmc_traffic(workload):
     return d.get("hbm_bytes_per_step"), os.path.relpath(files[-1], ROOT)
 
 
+def fabric_ceiling(dev, ev, src, dst, nbytes, reps=5):
+    """This chip's copy rate, measured live through the product's own copyBufferToBuffer (one-shot 16-byte nontemporal streaming
+    kernel, kern_generic.hpp stream_copy_kernel): GB/s of read + write traffic.  It is the ceiling for ANY kernel's fabric traffic on
+    this box — what `roofline.attainable` prices the transform against, next to (never instead of) the 8 TB/s roofline."""
+    nbytes = (min(nbytes, 8 << 30) // 16) * 16
+    enc = dev.createCommandEncoder()
+    enc.copyBufferToBuffer(src, 0, dst, 0, nbytes)
+    cmds = enc.finish()
+    dev.queue.submit([cmds])
+    dev.queue.onSubmittedWorkDone()
+    a, b = ev.create(), ev.create()
+    ev.record(a, dev.stream)
+    for _ in range(reps):
+        dev.queue.submit([cmds])
+    ev.record(b, dev.stream)
+    dev.queue.onSubmittedWorkDone()
+    ms = ev.elapsed_ms(a, b)
+    cmds.release()
+    return 2.0 * nbytes * reps / (ms / 1e3) / 1e9, nbytes
+
+
 def time_single_pass(mi355fft, dev, ev, opts, inp, out, which, reps):
     """live hipEvent timing of ONE of the two pass kernels (MI355FFT_ONLY_PASS planner aid): avg us per launch"""
     os.environ["MI355FFT_ONLY_PASS"] = str(which)
@@ -400,12 +421,14 @@ def main():
         step_dev_s = dev_max / args.steps
         achieved = bytes_per_point * float(n) * batch / step_dev_s / 1e9
         traffic, traffic_src = pmc_traffic(args.workload)
-        fused = ("xcd-fused" in route or "xcd-r2c" in route) and launches == 2
+        fused = ("xcd-fused" in route or "xcd-r2c" in route or "xcd-c2r" in route) and launches == 2
         resident = "xcd-resident" in route and launches == 2
         if resident:
             dominant, dominant_launches = "fft_xcd_res_kernel (transform resident in one XCD's registers + LDS between its passes, hand-offs through the L2)", 1
         elif fused:
-            dominant, dominant_launches = "fft_xcd_fused_kernel (pass A + XCD barrier + pass B in one persistent launch)", 1
+            kname = ("fft_xcd_rt_r2c_kernel" if "xcd-r2c-rt" in route else "fft_xcd_rt_c2r_kernel" if "xcd-c2r-rt" in route else "fft_xcd_rt_kernel" if "xcd-fused-rt" in route
+                     else "fft_xcd_hx_kernel" if "xcd-fused-2wg" in route else "fft_xcd_r2c_kernel" if "xcd-r2c" in route else "fft_xcd_c2r_kernel" if "xcd-c2r" in route else "fft_xcd_fused_kernel")
+            dominant, dominant_launches = kname + " (pass A + XCD barrier + pass B in one persistent launch)", 1
         elif "xcd-fused" in route:
             dominant, dominant_launches = "fft_xcd_fused_kernel, then " + route.split("]")[-1].strip() + " kernel", launches - 1
         elif "two-pass" in route:
@@ -434,6 +457,19 @@ def main():
             line["roofline"]["note"] = ("one fft_xcd_fused_kernel launch per step carries the whole batch (column FFTs -> per-XCD workspace slot -> "
                                         "XCD barrier -> four-step roots + row FFTs); the only other launch of a step is the 8 KiB zero_kernel "
                                         "that resets its control block (<3 us), so the step's device time is that kernel's launch duration")
+        try:
+            ceil_gbs, ceil_bytes = fabric_ceiling(dev, ev, inp, out, min(in_bytes, out_bytes))
+            moved = (traffic / (float(n) * batch)) if traffic else None          # bytes per point through the fabric (PMC passes)
+            line["roofline"]["attainable"] = {
+                "fabric_ceiling_GBps": ceil_gbs, "fabric_ceiling_source": f"copyBufferToBuffer of {ceil_bytes >> 20} MiB timed in this run (read + write bytes / device time)",
+                "bytes_per_point_moved": moved,
+                "moved_GBps": (moved * float(n) * batch / step_dev_s / 1e9) if moved else None,
+                "frac_of_attainable": (moved * float(n) * batch / step_dev_s / 1e9 / ceil_gbs) if moved else None,
+                "ceiling_for_this_traffic_frac_of_peak": (bytes_per_point / moved * ceil_gbs / HBM_PEAK_GBS) if moved else None,
+                "note": "frac (of the 8 TB/s roofline, algorithmic bytes) is the figure of merit; this block says how much of the gap is the chip's copy ceiling "
+                        "and how much is traffic beyond the algorithmic bytes (the four-step intermediate crosses the fabric once in each direction)"}
+        except Exception as e:   # never lose the line over the side measurement
+            line["roofline"]["attainable"] = {"error": str(e)}
         if per_kernel:
             line["roofline"]["per_kernel"] = per_kernel
             line["roofline"]["note"] = ("a launch in the roofline sense is the pass A + pass B pair that moves each point in and out once: "

@@ -333,7 +333,9 @@ def test_c2c_bluestein_lengths(fft, dev, oracle, monkeypatch, n, fused):
             w = np.fft.fft(c) if direction == "forward" else np.fft.ifft(c)
             want = np.stack([w.real, w.imag], axis=-1).reshape(-1)
         l2, mx = oracle.rel_l2(got, want), oracle.rel_max(got, want)
-        assert l2 <= 1e-5 and mx <= 2e-5, f"bluestein N={n} {direction}: {l2:.2e} {mx:.2e}"
+        # north_star's bar in both norms (r02 had loosened rel_max to 2e-5 here; measured against an f64 FFT the route is at
+        # 1-5e-7 in both norms for every length of this list, fused or not: profiles/r03_bluestein_error.log)
+        assert l2 <= 1e-5 and mx <= 1e-5, f"bluestein N={n} {direction}: {l2:.2e} {mx:.2e}"
         oracle.assert_close_elementwise(got, want, 3e-4 * max(1.0, float(np.max(np.abs(want))) / 30), 3e-4, f"bluestein N={n}")
 
 
@@ -705,6 +707,30 @@ def test_cfg5_shard_full_size_properties(fft, dev, oracle):
         pl.destroy()
     for b in (x, spec, back):
         b.destroy()
+
+
+def test_copy_buffer_to_buffer_streaming_kernel(fft, dev):
+    """copyBufferToBuffer: 16-byte-aligned ranges of 1 MiB and more take the one-shot streaming kernel (ragged last slab, offsets on both
+    sides), anything else the runtime copy; bit-exact, bytes around the destination range untouched"""
+    rng = np.random.default_rng(7)
+    for nbytes, so, do in (((1 << 20) + 16 * 37, 48, 16), ((5 << 20) + 16, 0, 1024), ((1 << 20) + 4, 16, 16), (4096, 4, 8)):
+        n = nbytes // 4
+        src = rng.standard_normal(n + 64).astype(np.float32)
+        sb = dev.createBuffer({"size": src.nbytes})
+        db = dev.createBuffer({"size": src.nbytes + 4096})
+        dev.queue.writeBuffer(sb, 0, src)
+        guard = np.full((src.nbytes + 4096) // 4, -7.0, dtype=np.float32)
+        dev.queue.writeBuffer(db, 0, guard)
+        enc = dev.createCommandEncoder()
+        enc.copyBufferToBuffer(sb, so, db, do, nbytes)
+        dev.queue.submit([enc.finish()])
+        dev.queue.onSubmittedWorkDone()
+        got = fft.downloadF32(dev, db, guard.size, 0)
+        want = guard.copy()
+        want[do // 4:do // 4 + n] = src[so // 4:so // 4 + n]
+        assert np.array_equal(got, want), (nbytes, so, do)
+        sb.destroy()
+        db.destroy()
 
 
 def test_batches_of_2p24_lines(fft, dev, oracle):

@@ -65,6 +65,13 @@ struct HipLauncher {
   }
   void copy(void* dst, const void* src, size_t bytes) {
     if (prepare_only || status != hipSuccess) return;
+    // large aligned, non-overlapping ranges: the one-shot streaming kernel (kern_generic.hpp); anything else: the runtime's copy
+    const uintptr_t d = reinterpret_cast<uintptr_t>(dst), s = reinterpret_cast<uintptr_t>(src);
+    if (bytes >= (1u << 20) && bytes % 16 == 0 && d % 16 == 0 && s % 16 == 0 && (d + bytes <= s || s + bytes <= d)) {
+      const unsigned long long n16 = bytes / 16, slabs = (n16 + 1023) / 1024;
+      launch(stream_copy_kernel, (unsigned)(slabs < 0x3fffffull ? slabs : 0x3fffffull), 256u, 0u, (const f4v*)src, (f4v*)dst, n16);
+      return;
+    }
     const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
     if (e != hipSuccess) status = e;
   }

@@ -64,6 +64,22 @@ static __global__ void __launch_bounds__(256) stockham_stage_kernel(const StageA
   }
 }
 
+// copyBufferToBuffer for 16-byte-aligned ranges (WebGPU GPUCommandEncoder.copyBufferToBuffer, which the reference's downloadComplex
+// and bench loops use): one short-lived workgroup per 16 KB slab, 16-byte nontemporal accesses — the form that reaches this chip's
+// copy ceiling (6.4-6.5 TB/s of read + write traffic against 4.9-5.5 for hipMemcpy D2D, profiles/r02_copy_ceiling.log).  bench.py
+// times it live as the fabric ceiling next to the transform (`roofline.attainable`).
+typedef float f4v __attribute__((ext_vector_type(4)));
+static __global__ void __launch_bounds__(256) stream_copy_kernel(const f4v* __restrict__ src, f4v* __restrict__ dst, unsigned long long n16) {
+  for (unsigned long long slab = blockIdx.x; slab * 1024ull < n16; slab += gridDim.x) {
+    const unsigned long long base = slab * 1024ull + threadIdx.x;
+    f4v v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (base + 256ull * j < n16) v[j] = __builtin_nontemporal_load(src + base + 256ull * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (base + 256ull * j < n16) __builtin_nontemporal_store(v[j], dst + base + 256ull * j);
+  }
+}
+
 // data[i] *= s  (float granularity so the same kernel serves real and complex buffers)
 static __global__ void __launch_bounds__(256) scale_kernel(float* data, long long count, float s) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
