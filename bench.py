@@ -251,11 +251,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="replay the op list instead of a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    gpus_given = any(a == "--gpus" or a.startswith("--gpus=") for a in sys.argv[1:])
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` on its own: start the N ranks as CHILD processes (one per GPU) before anything here has
         # touched the GPU — this parent never imports torch or opens a device — and exit with the launcher's code.
         sys.exit(launch_ranks(args.gpus))
+    if "WORLD_SIZE" in os.environ and not gpus_given:
+        args.gpus = int(os.environ["WORLD_SIZE"])       # started under torch.distributed.run without --gpus: adopt its world size
     if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     if os.environ.get("MI355FFT_BENCH_STUB"):   # CPU-tier test of the launcher plumbing: no device work at all
@@ -427,7 +430,7 @@ def main():
             dominant, dominant_launches = "fft_xcd_res_kernel (transform resident in one XCD's registers + LDS between its passes, hand-offs through the L2)", 1
         elif fused:
             kname = ("fft_xcd_rt_r2c_kernel" if "xcd-r2c-rt" in route else "fft_xcd_rt_c2r_kernel" if "xcd-c2r-rt" in route else "fft_xcd_rt_kernel" if "xcd-fused-rt" in route
-                     else "fft_xcd_hx_kernel" if "xcd-fused-2wg" in route else "fft_xcd_r2c_kernel" if "xcd-r2c" in route else "fft_xcd_c2r_kernel" if "xcd-c2r" in route else "fft_xcd_fused_kernel")
+                     else "fft_xcd_rt1k_kernel" if "xcd-fused-rt32" in route else "fft_xcd_hx_kernel" if "xcd-fused-2wg" in route else "fft_xcd_r2c_kernel" if "xcd-r2c" in route else "fft_xcd_c2r_kernel" if "xcd-c2r" in route else "fft_xcd_fused_kernel")
             dominant, dominant_launches = kname + " (pass A + XCD barrier + pass B in one persistent launch)", 1
         elif "xcd-fused" in route:
             dominant, dominant_launches = "fft_xcd_fused_kernel, then " + route.split("]")[-1].strip() + " kernel", launches - 1
@@ -454,7 +457,7 @@ def main():
             line["roofline"]["note"] = ("one fft_xcd_res_kernel launch per step carries the whole batch; the only other launch of a step is the 36 KiB zero_kernel "
                                         "that resets its control block (<3 us), so the step's device time is that kernel's launch duration")
         if fused:
-            line["roofline"]["note"] = ("one fft_xcd_fused_kernel launch per step carries the whole batch (column FFTs -> per-XCD workspace slot -> "
+            line["roofline"]["note"] = ("one " + kname + " launch per step carries the whole batch (column FFTs -> per-XCD workspace slot -> "
                                         "XCD barrier -> four-step roots + row FFTs); the only other launch of a step is the 8 KiB zero_kernel "
                                         "that resets its control block (<3 us), so the step's device time is that kernel's launch duration")
         try:

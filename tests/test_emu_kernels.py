@@ -606,7 +606,7 @@ def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")
 
 
-@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(21, "1024x2048", 2, 2, 1, 2), (21, "1024x2048", 3, 1, 1, 1), (22, "2048x2048", 2, 1, 1, 2), (22, "2048x2048", 4, 2, 2, 2)])
+@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(21, "1024x2048", 3, 1, 1, 1), (22, "2048x2048", 4, 2, 2, 2)])
 def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots):
     """2048-point sides on register-resident 16-line tiles (kern_regtile.hpp): 64-point DFT in registers, one exchange through LDS in
     two halves, radix-32 stage; 2^21 = LDS-resident pass A + register-tile pass B, 2^22 = register tiles on both passes.
@@ -625,12 +625,12 @@ def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-rt {label} {direction}")
 
 
-@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (3, 1, 2, 1)])
-def test_c2c_xcd_two_workgroups_per_cu(oracle, monkeypatch, cus, xcds, split, slots):
-    """N = 2^20 on register tiles with the exchange in two 64 KB halves (kern_regtile.hpp fft_xcd_hx_kernel): 72 KB of LDS and 128
-    VGPRs per workgroup, two workgroups per CU (grid = 2 x CUs)"""
+@pytest.mark.parametrize("cus,xcds,split,slots,hx,label", [(2, 2, 1, 2, 1, "2wg"), (3, 1, 2, 1, 1, "2wg"), (2, 2, 1, 2, 2, "rt32"), (3, 1, 1, 1, 2, "rt32")])
+def test_c2c_xcd_two_workgroups_per_cu(oracle, monkeypatch, cus, xcds, split, slots, hx, label):
+    """N = 2^20 on register tiles (kern_regtile.hpp): hx=1 the exchange in two 64 KB halves, 72 KB of LDS and 128 VGPRs per workgroup,
+    two workgroups per CU (fft_xcd_hx_kernel); hx=2 tiles of 32 lines, 256-byte segments (fft_xcd_rt1k_kernel)"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
-    monkeypatch.setenv("MI355_EMU_XCD_HX", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_HX", str(hx))
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
@@ -640,8 +640,8 @@ def test_c2c_xcd_two_workgroups_per_cu(oracle, monkeypatch, cus, xcds, split, sl
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
         desc = _abi.make_desc("c2c", [n], batch, direction, norm)
         got, route, launches = emu.run_plan(desc, x, x.size)
-        assert route.startswith("xcd-fused-2wg[N=1024x1024]") and launches == 2, route
-        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-2wg {direction}")
+        assert route.startswith(f"xcd-fused-{label}[N=1024x1024]") and launches == 2, route
+        check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-{label} {direction}")
 
 
 @pytest.mark.parametrize("lg,label,cus", [(15, "128x256", 3), (16, "256x256", 2), (17, "256x512", 5)])

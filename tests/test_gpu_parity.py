@@ -130,10 +130,11 @@ FUSED_LG = (15, 16, 17, 18, 19, 20, 21, 22)   # 15-17: solo mode; 21, 22 (r03): 
 @pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     """four-step sizes on both routes: the two-launch route and (where an instance exists) the XCD-fused launch"""
-    if fused and lg not in FUSED_LG or (fused == 2 and lg != 21):
+    if fused and lg not in FUSED_LG or (fused == 2 and lg not in (20, 21)):
         pytest.skip("no fused instance")
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(min(fused, 1)))
-    monkeypatch.setenv("MI355FFT_XCD_RT", "0" if fused == 2 else "1")   # fused=2: the LDS-resident 1024 x 2048 instance the register tiles replaced (8-line tiles)
+    monkeypatch.setenv("MI355FFT_XCD_RT", "0" if fused == 2 else "1")   # fused=2: the LDS-resident instances the register tiles replaced (2^21: 8-line tiles;
+    monkeypatch.setenv("MI355FFT_XCD_HX", "0" if fused == 2 else "2")   #          2^20: 16 x 1024 tiles in LDS)
     monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # ... and so would 2^15 (kern_line32k.hpp, test_c2c_line32k)
     monkeypatch.setenv("MI355FFT_SOLO_MAX_KB", "1024")    # solo mode up to 2^17 as in round 1 (default since r02: up to 2^16, 2^17 shared)
@@ -141,19 +142,21 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused-rt[" if lg >= 21 and fused == 1 else "xcd-fused[") if fused else "two-pass["), route
+        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused-rt[" if lg >= 21 and fused == 1 else "xcd-fused-rt32[" if lg == 20 and fused == 1 else "xcd-fused[") if fused else "two-pass["), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
-def test_c2c_two_workgroups_per_cu(fft, dev, oracle, monkeypatch):
-    """N = 2^20 on the opt-in register-tile kernel with two workgroups per CU (kern_regtile.hpp fft_xcd_hx_kernel; measured slower
-    than the shipped kernel, profiles/r03_headline_2wg_ab.log): 19 transforms over the groups, both directions, against the oracle"""
-    monkeypatch.setenv("MI355FFT_XCD_HX", "1")
+@pytest.mark.parametrize("hx,label", [(1, "2wg"), (2, "rt32")])
+def test_c2c_two_workgroups_per_cu(fft, dev, oracle, monkeypatch, hx, label):
+    """N = 2^20 on the opt-in register-tile kernels (kern_regtile.hpp): hx=1 two workgroups per CU (fft_xcd_hx_kernel; measured slower
+    than the shipped kernel, profiles/r03_headline_2wg_ab.log), hx=2 tiles of 32 lines (fft_xcd_rt1k_kernel): 19 transforms over the
+    groups, both directions, against the oracle"""
+    monkeypatch.setenv("MI355FFT_XCD_HX", str(hx))
     n, batch = 1 << 20, 19
     x = oracle.random_complex_batch(n, batch, 0xE520).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith("xcd-fused-2wg[N=1024x1024]") and launches == 2, route
+        assert route.startswith(f"xcd-fused-{label}[N=1024x1024]") and launches == 2, route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} {direction}")
 
 
@@ -931,7 +934,7 @@ def test_xcd_timeout_fails_the_readback_then_falls_back(fft, dev, oracle, monkey
         inp = mi355fft.uploadComplex(d2, x)
         out = d2.createBuffer({"size": x.nbytes})
         plan = mi355fft.createPlan(d2, {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none"})
-        assert plan.describe()[0].startswith("xcd-fused["), plan.describe()
+        assert plan.describe()[0].startswith("xcd-fused"), plan.describe()
         enc = d2.createCommandEncoder()
         plan.exec(enc, {"input": inp, "output": out})
         cb = enc.finish()

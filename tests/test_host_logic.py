@@ -120,8 +120,8 @@ def test_xcd_resident_route_is_opt_in_and_needs_whole_xcds(monkeypatch):
     import emu_harness as emu
     from mi355fft import _abi
     d = _abi.make_desc("c2c", [1 << 20], 64, "forward", "none")
-    assert emu.plan_only(d)[0].startswith("xcd-fused[N=1024x1024]")
+    assert emu.plan_only(d)[0].startswith("xcd-fused-rt32[N=1024x1024]")
     monkeypatch.setenv("MI355FFT_XCD_RES", "1")
     route, launches, work = emu.plan_only(d)
     assert route.startswith("xcd-resident[N=1024x1024,depth=4]") and launches == 2 and work >= 16 * 4 * (1 << 20)
-    assert emu.plan_only(d, compute_units=250)[0].startswith("xcd-fused[")      # not a multiple of 32 CUs: no resident groups
+    assert emu.plan_only(d, compute_units=250)[0].startswith("xcd-fused")      # not a multiple of 32 CUs: no resident groups

@@ -17,7 +17,7 @@ run() {  # tag workload steps launches-json
 want() { [ $# -eq 0 ] && return 0; local t=$1; shift; for a in $TAGS; do [ "$a" = "$t" ] && return 0; done; return 1; }
 TAGS="$*"
 sel() { [ -z "$TAGS" ] && return 0; for a in $TAGS; do [ "$a" = "$1" ] && return 0; done; return 1; }
-sel cfg3 && run cfg3 c2c_2p20_b4096 5 '{"fft_xcd_fused_kernel": 1}'
+sel cfg3 && run cfg3 c2c_2p20_b4096 5 '{"fft_xcd_rt1k_kernel": 1, "fft_xcd_fused_kernel": 1}'
 sel cfg2 && run cfg2 c2c_1024_b65536 20 '{"fft_lines_kernel": 1}'
 sel cfg5 && run cfg5 r2c_2p22_b1024 5 '{"fft_xcd_rt_r2c_kernel": 1}'
 sel c2c22 && run c2c22 c2c_2p22_b512 5 '{"fft_xcd_rt_kernel": 1}'

@@ -126,7 +126,7 @@ int sync_and_check(mi355fft_device* dev) {
       dev->xcd_disabled = true;
       return fail(MI355FFT_ERR_HIP, "XCD-fused FFT kernel gave up waiting (%s%s%s): its workgroups were not all co-resident; results of that submit are "
                   "invalid.  Plans on this device now use the routes without cross-workgroup synchronisation: record and submit again.", (word & 1u) ? "registration " : "", (word & 2u) ? "barrier " : "",
-                  (word & 4u) ? "group-size" : "");
+                  (word & 16u) ? "registration-count-overflow" : (word & 4u) ? "group-size" : "");
     }
   }
   return MI355FFT_OK;

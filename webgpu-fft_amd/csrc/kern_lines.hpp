@@ -655,8 +655,8 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
           // f64-built table behind the LO roots that the DCT-III kernel uses: two more dependent loads per bin pair in this store
           // loop measured 205 vs 245 G points/s at N = 1024 (profiles/r02_trig_probes.log)
           float sn, cs;
-#ifdef MI355_HOST_EMU
-          { const cf ph = a.tw_lo[1024 + m]; cs = ph.x; sn = ph.y; }
+#ifdef MI355_HOST_EMU   /* the shipped arithmetic's dominant error — the argument rounded to f32 — reproduced on the host (an exact evaluation of the f32 argument) */
+          { const float arg = -(float)m / (float)(2 * NREAL); cs = (float)std::cos(3.14159265358979323846 * (double)arg); sn = (float)std::sin(3.14159265358979323846 * (double)arg); }
 #else
           sincospif(-(float)m / (float)(2 * NREAL), &sn, &cs);
 #endif

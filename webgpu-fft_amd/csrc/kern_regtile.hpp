@@ -641,4 +641,154 @@ __global__ void __launch_bounds__(HxCfg::THREADS, MI355_HX_WAVES) fft_xcd_hx_ker
   }
 }
 
+// ---- N = 1024 x 1024 on register tiles of 32 lines (256-byte segments) -----------------------------------------------------------
+// Same scheme as the 16 x 2048 tiles above for the headline's size: a 32 x 1024 tile (2^15 points) in the registers of 512 threads,
+// two radix-32 butterflies per thread and stage (1024 = 32 * 32), the one exchange through LDS in two halves of 128 KB (outputs
+// p < 16 of every butterfly, then p >= 16).  Every global access is a run of 32 lanes x 8 bytes (or 16 lanes x 16 bytes) = 256 bytes
+// where the LDS-resident 16 x 1024 tiles of kern_xcd.hpp move 128, and a workgroup has twice the bytes in flight.
+//   column side:  line = t mod 32, h = t div 32 (0..15): producers u = h, h + 16; consumers j2 = h (first half), h + 16 (second)
+//   rows as input: line = t div 16, hh = t mod 16: producers u = 2 hh, 2 hh + 1 — ONE 16-byte load per pair
+// Exchange layout: slot(line, p', u) = u * 512 + p' * 32 + ((line + u div 2) mod 32): 16-lane writer groups (lines at fixed u, or hh
+// at fixed line) hit 16 different 8-byte slots mod 16, 32-lane reader groups (32 lines) 32 different ones mod 32.
+#ifndef MI355_RT1K_NT_OUT
+#define MI355_RT1K_NT_OUT MI355_XCD_NT
+#endif
+#ifndef MI355_RT1K_NT_IN
+#define MI355_RT1K_NT_IN MI355_RT_NT_IN
+#endif
+#ifndef MI355_RT1K_W_NT
+#define MI355_RT1K_W_NT 0      /* experiment: nontemporal accesses to the intermediate */
+#endif
+struct Rt1kCfg {
+  static constexpr int N = 1024, T = 32, THREADS = 512;
+  static constexpr int HALF_ELEMS = T * 32 * 16;
+  static constexpr int TW1_ELEMS = 31 * 32;
+  static constexpr int LDS_BYTES = (HALF_ELEMS + TW1_ELEMS) * 8 + 64;
+};
+MI_DEV int rt1k_slot(int line, int pl, int u) { return u * 512 + pl * 32 + ((line + (u >> 1)) & 31); }
+
+// producers (line, ua), (line, ub) with outputs va[p], vb[p]; consumers (cl, h) in the first half and (cl, h + 16) in the second.
+// `mid()` runs between the halves' reads, when consumer 0's inputs are in w and the second half is on its way through LDS.
+template <class Mid>
+MI_DEV void rt1k_exchange(const cf (&va)[32], const cf (&vb)[32], cf (&w)[32], cf* xb, int line, int ua, int ub, int cl, int h, Mid&& mid) {
+  const int wa = rt1k_slot(line, 0, ua), wb2 = rt1k_slot(line, 0, ub);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) { xb[wa + p * 32] = va[p]; xb[wb2 + p * 32] = vb[p]; }
+  __syncthreads();
+#pragma unroll
+  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 512 + h * 32 + ((cl + (uu >> 1)) & 31)];
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 16; ++p) { xb[wa + p * 32] = va[16 + p]; xb[wb2 + p * 32] = vb[16 + p]; }
+  __syncthreads();
+  MI_SCHED_FENCE();
+  mid();
+  MI_SCHED_FENCE();
+#pragma unroll
+  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 512 + h * 32 + ((cl + (uu >> 1)) & 31)];
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const XcdFusedArgs f) {
+  MI_SMEM_DECL(smem);
+  cf* xb = reinterpret_cast<cf*>(smem);
+  cf* tw1 = xb + Rt1kCfg::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + Rt1kCfg::TW1_ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < Rt1kCfg::TW1_ELEMS; i += Rt1kCfg::THREADS) tw1[i] = f.tw_a[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+  constexpr unsigned N1 = 1024, N2 = 1024, NT = 32;
+  const bool two_slots = f.slots != 1u;
+  cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
+  const int cl = t & 31, h = t >> 5;        // column-side map
+  const int rl = t >> 4, hh = t & 15;       // row-side map
+  const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
+  const auto stage1 = [&](cf (&w)[32], int j2) {
+    int ti = j2; MI_OPAQUE_LANE_INT(ti);     // (not loop-invariant for the optimiser: hoisted, the 31 roots would pin 62 registers)
+#pragma unroll
+    for (int q = 1; q < 32; ++q) w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]);
+    fft_radix<32>(w);
+  };
+  unsigned k = 0;
+  for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
+    cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)f.N;
+    const cf* const x = f.in + tr * f.in_pitch;
+    // ---- phase A: 32 adjacent columns per tile ----
+    for (unsigned tile = rank; tile < NT; tile += gsize) {
+      cf va[32], vb[32], w[32];
+      {
+        const cf* p = x + tile * 32u;
+        const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          va[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
+          vb[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff));
+        }
+      }
+      fft_radix<32>(va);
+      fft_radix<32>(vb);
+      cf* const po = W + tile * 32u;
+      const unsigned so = (unsigned)h * N2 + (unsigned)cl;
+      rt1k_exchange(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
+        stage1(w, h);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q) * N2) + so, w[q]);
+      });
+      stage1(w, h + 16);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q + 16) * N2) + so, w[q]);
+      __syncthreads();
+    }
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    // ---- phase B: 32 adjacent rows per tile, four-step roots on load, transposed store ----
+    cf* const y = f.out + tr * f.out_pitch;
+    for (unsigned tile = rank; tile < NT; tile += gsize) {
+      cf va[32], vb[32], w[32];
+      {
+        const unsigned k1 = tile * 32u + (unsigned)rl;
+        const cf* p = W + (size_t)(tile * 32u) * N2;
+        const unsigned lo = (unsigned)rl * N2 + 2u * (unsigned)hh;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          const cf4 pr = *reinterpret_cast<const cf4*>(sgpr_base(p + 32 * q) + lo);     // elements 2hh + 32q and 2hh + 1 + 32q of row k1
+          va[q] = cf{pr.x, pr.y}; vb[q] = cf{pr.z, pr.w};
+        }
+        const cf step = root(k1 * 32u), one = root(k1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          cf ra = root(k1 * (unsigned)(2 * hh + 256 * g));
+          cf rb = cmul(ra, one);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            va[8 * g + j] = cmul(va[8 * g + j], ra); vb[8 * g + j] = cmul(vb[8 * g + j], rb);
+            if (j < 7) { ra = cmul(ra, step); rb = cmul(rb, step); }
+          }
+        }
+      }
+      fft_radix<32>(va);
+      fft_radix<32>(vb);
+      cf* const po = y + tile * 32u;
+      const unsigned so = (unsigned)h * N1 + (unsigned)cl;
+      const auto store = [&](cf (&ww)[32], unsigned off) {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          cf r = ww[q];
+          if (f.scale != 1.0f) r = r * f.scale;
+          st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
+        }
+      };
+      rt1k_exchange(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] { stage1(w, h); store(w, 0u); });
+      stage1(w, h + 16);
+      store(w, 16u);
+      __syncthreads();
+    }
+    if (!two_slots) {
+      xcd_arrive(&f.ctl->bar[gslot][1]);
+      if (!xcd_wait(&f.ctl->bar[gslot][1], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
+    }
+  }
+}
+
 }  // namespace mi355

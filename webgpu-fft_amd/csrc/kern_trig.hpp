@@ -41,8 +41,10 @@ struct TrigArgs {
 #endif
 MI_DEV cf trig_phase(double turns_half) {
   cf r;
-#ifdef MI355_HOST_EMU
+#if defined(MI355_HOST_EMU) && MI355_TRIG_F64_PHASE
   r.x = (float)std::cos(3.14159265358979323846 * turns_half); r.y = (float)std::sin(3.14159265358979323846 * turns_half);
+#elif defined(MI355_HOST_EMU)   /* as shipped: the argument rounded to f32 first (sincospif's input), evaluated exactly */
+  r.x = (float)std::cos(3.14159265358979323846 * (double)(float)turns_half); r.y = (float)std::sin(3.14159265358979323846 * (double)(float)turns_half);
 #elif MI355_TRIG_F64_PHASE
   double s, c;
   sincospi(turns_half, &s, &c);

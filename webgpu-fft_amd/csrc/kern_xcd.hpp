@@ -155,9 +155,12 @@ MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, u
     const unsigned x = MI_XCC_ID() & 15u;
     unsigned ok = 0, r = 0;
     unsigned long long snap = 0;
-    if (x < 8u) {   // gfx950 has 8 XCDs; anything else is reported, never mis-grouped
+    // (a byte per XCC id: a 256th registration on one id would carry into its neighbour's count and mis-group silently, so grids
+    // beyond 8 x 255 workgroups and a full byte are refused: sticky bit 4 -> queue_wait reports it)
+    if (x < 8u && gridDim.x <= 8u * 255u) {   // gfx950 has 8 XCDs; anything else is reported, never mis-grouped
       const unsigned long long old = MI_ATOMIC_ADD_U64(&ctl->reg_packed, 1ull << (8u * x));
       r = (unsigned)(old >> (8u * x)) & 0xffu;
+      if (r == 0xffu) MI_ATOMIC_OR_U32(sticky, 16u);
       for (unsigned it = 0; it < spin_limit; ++it) {
         snap = MI_ATOMIC_LOAD_U64(&ctl->reg_packed);
         unsigned total = 0;
@@ -182,7 +185,7 @@ MI_DEV bool xcd_register(XcdCtl* ctl, unsigned split_arg, unsigned spin_limit, u
       groups += nsub;
     }
     s_words[0] = x * split + sub; s_words[1] = mine; s_words[2] = gsz; s_words[3] = ok; s_words[4] = gi; s_words[5] = groups;
-    if (!ok) MI_ATOMIC_OR_U32(sticky, 1u);
+    if (!ok) MI_ATOMIC_OR_U32(sticky, gridDim.x > 8u * 255u ? 16u : 1u);
   }
   __syncthreads();
   return s_words[3] != 0;

@@ -56,6 +56,7 @@ namespace mi355 {
 // a per-lane value the optimiser must treat as freshly defined here: loads indexed by it are not loop-invariant (the 31 + 31 stage
 // roots of a thread are: hoisted out of the transform loop they would pin 124 registers for the whole kernel)
 #define MI_OPAQUE_LANE_INT(i) asm volatile("" : "+v"(i))
+#define MI_COMPILER_ACQUIRE() do { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); asm volatile("" ::: "memory"); } while (0)
 template <class T> MI_DEV T* sgpr_base(T* p) {
   unsigned long long a = (unsigned long long)p;
   asm volatile("" : "+s"(a));
@@ -73,6 +74,7 @@ MI_DEV cf ld_sc1(const cf* p) {
 #else
 #define MI_UNIFORM_U32(v) ((unsigned)(v))
 #define MI_OPAQUE_LANE_INT(i) do { } while (0)
+#define MI_COMPILER_ACQUIRE() __atomic_thread_fence(__ATOMIC_ACQUIRE)
 template <class T> MI_DEV T* sgpr_base(T* p) { return p; }
 #define MI_WAVE_ONLY_SYNC() emu::sync_wave()
 #define MI_LDS_ATOMIC_ADD_U32(p, v) __atomic_fetch_add((p), (v), __ATOMIC_SEQ_CST)
@@ -111,6 +113,11 @@ MI_DEV bool res_wait(unsigned* counter, unsigned target, const XcdFusedArgs& f, 
   MI_WAVE_ONLY_SYNC();
   const bool ok = *(volatile unsigned*)s_flag != 0;
   MI_WAVE_ONLY_SYNC();   // the flag is re-used by this wave's next wait
+  // Invariant: the payload behind `counter` is read only AFTER the poll has seen the producers' bumps.  The payload loads are
+  // device-scope (sc1) loads served by the shared L2, so no cache maintenance is needed, but nothing above orders them for the
+  // COMPILER (relaxed atomics, volatile LDS flag): this fence is the compiler-visible ordering point (workgroup scope: no L2
+  // write-back, no L1 invalidate beyond what the sc1 loads do anyway).
+  MI_COMPILER_ACQUIRE();
   return ok;
 }
 // this wave's vector-memory operations are complete; the later of the two waves of a channel bumps the XCD-wide counter

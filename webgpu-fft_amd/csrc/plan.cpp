@@ -133,6 +133,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 16, 16, inv != 0, 512, (16 * 32 * 16 + 31 * 32) * 8 + 64, 0, 2}; r.push_back(m);
     }
     { XcdKernelMeta m{id++, 2048, 2048, {64, 32, 1}, {64, 32, 1}, 16, 16, false, 512, (16 * 32 * 32 + 31 * 64) * 8 + 64, 2, 1}; r.push_back(m); }   // c2r 2048 x 2048 (fft_xcd_rt_c2r_kernel)
+    for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 on 32-line register tiles (fft_xcd_rt1k_kernel): rt = 3
+      XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 0, 3}; r.push_back(m);
+    }
     return r;
   }();
   return reg;
@@ -169,7 +172,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_HX")) o.xcd_hx = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
-  if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v == 1 || v == 2) o.xcd_slots = v; }
+  if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v >= 0 && v <= 2) o.xcd_slots = v; }
   return o;
 }
 
@@ -313,11 +316,16 @@ struct Builder {
   //   src/dst may be the same location.  inverse => e^{+...}.  scale fused into the last launch.
   // groups per XCD for the fused kernels.  Measured (profiles/r01_xcd_fused_ab.log): more, smaller groups are better as long
   // as all their workspace slots together stay within the 256 MiB Infinity Cache (8 XCDs x split x slots x slot bytes)
-  int64_t xcd_split_for(uint64_t slot_bytes) const {
-    if (opt.xcd_split > 0) return opt.xcd_split;
-    int64_t split = 8;
-    while (split > 1 && (uint64_t)(8 * opt.xcd_slots * split) * slot_bytes > ((uint64_t)320 << 20)) split >>= 1;   // (r2c slots are N/2 + N2 points: a little over a power of two)
-    return split;
+  // r03 (profiles/r03_headline_rt32_ab.log): at EQUAL footprint, twice the groups with ONE slot each (two barriers per transform) beat
+  // half the groups with two slots (one barrier): c2c 2^20 184 -> 194 (LDS-resident kernel), 2^17 179 -> 192, r2c 2^21 216 -> 245,
+  // c2r 2^20 289 -> 300.  So: one slot per group, and as many groups per XCD (a power of two, at most 16) as keep all slots of the chip
+  // within the 256 MiB Infinity Cache.  The 2048-point register-tile instances keep two slots (their single group per XCD measured
+  // the same either way).  MI355FFT_XCD_SPLIT / MI355FFT_XCD_SLOTS override.
+  void xcd_groups(uint64_t slot_bytes, bool two_slot_default, int64_t& split, int64_t& slots) const {
+    slots = opt.xcd_slots > 0 ? opt.xcd_slots : (two_slot_default ? 2 : 1);
+    if (opt.xcd_split > 0) { split = opt.xcd_split; return; }
+    split = 16;
+    while (split > 1 && (uint64_t)(8 * slots * split) * slot_bytes > ((uint64_t)(two_slot_default ? 320 : 256) << 20)) split >>= 1;
   }
 
   // 2-D c2c planes [N1][N0] (axis 0 = N0 fastest) through the fused kernel's TWO_D instances; false if none applies
@@ -331,7 +339,7 @@ struct Builder {
     const LineKernelMeta mb = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, false, false, false, 0);
     const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb_2d << 10);
     if (!solo && !opt.xcd_shared) return false;
-    int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+    int64_t split = 1, grid = opt.compute_units, slots = 1;
     PtrRef wslots, ctl;
     if (solo) {
       const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
@@ -340,8 +348,8 @@ struct Builder {
       wslots = alloc_work((uint64_t)grid * N * 8);
       ctl = alloc_work(256);
     } else {
-      split = xcd_split_for((uint64_t)N * 8);
-      wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);
+      xcd_groups((uint64_t)N * 8, false, split, slots);
+      wslots = alloc_work((uint64_t)(16 * slots * split) * N * 8);
       ctl = alloc_work(40960);
       if (xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) grid *= 2;
     }
@@ -374,7 +382,7 @@ struct Builder {
     // small transforms: one workgroup per transform (solo mode, see emit_axis); the real line is N*4 bytes
     const bool solo = (uint64_t)N * 4 <= ((uint64_t)opt.solo_max_kb << 10) / (c2r ? 1 : 2) && opt.xcd_fused != 2;
     if (!solo && !opt.xcd_shared) return false;
-    int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+    int64_t split = 1, grid = opt.compute_units, slots = 1;
     PtrRef wslots, ctl;
     if (solo) {
       const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
@@ -383,8 +391,8 @@ struct Builder {
       wslots = alloc_work((uint64_t)grid * wsize * 8);
       ctl = alloc_work(256);
     } else {
-      split = xcd_split_for((uint64_t)wsize * 8);
-      wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * wsize * 8);
+      xcd_groups((uint64_t)wsize * 8, xm->rt == 1, split, slots);
+      wslots = alloc_work((uint64_t)(16 * slots * split) * wsize * 8);
       ctl = alloc_work(40960);
     }
     const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
@@ -654,7 +662,7 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry())
-        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx : opt.xcd_rt) && opt.xcd_shared))) xm = &m;
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
         const bool a_rt = xm->rt == 1 && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
@@ -664,7 +672,7 @@ struct Builder {
         // workgroup barrier, so no co-residency requirement and as many workgroups per CU as fit); larger ones are shared by
         // the groups of an XCD
         const bool solo = (uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2;
-        int64_t split = 1, grid = opt.compute_units, slots = opt.xcd_slots;
+        int64_t split = 1, grid = opt.compute_units, slots = 1;
         PtrRef wslots, ctl;
         if (solo) {
           const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>((160 * 1024) / xm->lds_bytes, 2048 / xm->threads), 4));
@@ -673,8 +681,8 @@ struct Builder {
           wslots = alloc_work((uint64_t)grid * N * 8);          // one slot per workgroup, all of them within the Infinity Cache
           ctl = alloc_work(256);
         } else {
-          split = xcd_split_for((uint64_t)N * 8);
-          wslots = alloc_work((uint64_t)(16 * opt.xcd_slots * split) * N * 8);   // slots per group x `split` groups per XCC id (16 ids)
+          xcd_groups((uint64_t)N * 8, xm->rt == 1, split, slots);
+          wslots = alloc_work((uint64_t)(16 * slots * split) * N * 8);   // slots per group x `split` groups per XCC id (16 ids)
           ctl = alloc_work(40960);
         }
         const int shift = N >= (1 << 20) ? 10 : lgf / 2;                // LO table of 2^shift roots, HI of N >> shift
@@ -692,7 +700,7 @@ struct Builder {
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
         if (!solo && opt.xcd_fused != 2 && ((xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) || xm->rt == 2)) grid *= 2;
         st.grid = (unsigned)grid;
-        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt == 3 ? "xcd-fused-rt32[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }

@@ -159,14 +159,15 @@ struct PlannerOptions {
   int xcd_res_depth = 4;               // exchange channels in flight per XCD (1, 2, 4): 1 MiB of L2-resident buffer each
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
   int xcd_rt = 1;                      // 2048-point sides on register tiles (kern_regtile.hpp) where an instance exists (0: the LDS-resident 8-line tiles / two-pass route)
-  int xcd_hx = 0;                      // N = 2^20: the register-tile kernel with two workgroups per CU (kern_regtile.hpp fft_xcd_hx_kernel) instead of the LDS-resident fused kernel
+  int xcd_hx = 2;                      // N = 2^20: 2 = 32-line register tiles (kern_regtile.hpp fft_xcd_rt1k_kernel; r03 default: 199 vs 194 GPoints/s), 1 = two workgroups per CU on 16-line
+                                       // register tiles (fft_xcd_hx_kernel: 171), 0 = the LDS-resident fused kernel (kern_xcd.hpp)
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
   int xcd_r2c = 1;                     // r2c: real four-step kernel where an instance exists (0: half-length c2c + split)
   int solo_cap_mb = 256;               // solo mode: all workgroups' workspace slots together (MiB) = the Infinity Cache (r02: 2^16 203 vs 189 GPoints/s with 1024; below 256 occupancy collapses)
   int solo_max_kb_2d = 1024;           // 2-D planes up to this size run in solo mode (unchanged from round 1)
   int solo_max_kb = 512;               // c2c transforms (and 2-D planes) up to this size run in solo mode; r2c up to half of it, c2r up to this many KB of REAL line
                                        // (r02, same box: c2c 2^17 shared 171 vs solo 147, r2c 2^17 281 vs 250, c2r 2^17 solo 318 vs 278, c2c 2^16 solo 206 vs 156)
-  int xcd_slots = 2;                   // workspace slots per group (2: one barrier per transform; 1: two barriers)
+  int xcd_slots = 0;                   // workspace slots per group: 0 = per route (r03: one slot and twice the groups; the 2048-point register-tile instances two), 1: two barriers per transform, 2: one barrier
   int mixed_ct = 1;                    // mixed-radix lengths with a compile-time-plan instance (kern_mixed_ct.hpp) use it (dense lines)
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
