@@ -156,6 +156,7 @@ int emu_run_plan(const mi355fft_plan_desc* desc, void* input, uint64_t input_byt
   if (const char* e = std::getenv("MI355_EMU_XCD_2D")) opt.xcd_2d = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_RT")) opt.xcd_rt = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_XCD_HX")) opt.xcd_hx = std::atoi(e);
+  if (const char* e = std::getenv("MI355_EMU_CONV_PIPELINE")) opt.conv_pipeline = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_LINES_R2C")) opt.lines_r2c = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_LINES_C2R")) opt.lines_c2r = std::atoi(e);
   if (const char* e = std::getenv("MI355_EMU_TRIG_REAL")) opt.trig_real = std::atoi(e);

@@ -235,6 +235,28 @@ def test_fftconv_product_fused_into_forward_lines(oracle, monkeypatch, shape, ks
     assert oracle.rel_l2(got, old) < 1e-6
 
 
+@pytest.mark.parametrize("ks,mode,K,layout,cus", [(None, "convolution", 1, "kernel-major", 2), ([1000], "correlation", 2, "batch-major", 3)])
+def test_fftconv_pipeline_2p20(oracle, monkeypatch, ks, mode, K, layout, cus):
+    """2^20-point circular lines: forward transform, product with the kernel spectra and inverse transforms in ONE persistent launch
+    (kern_regtile.hpp fft_xcd_conv1m_kernel: the spectrum tile of the forward pass B is the input tile of the inverse pass A and never
+    leaves the registers); K = 2 re-runs the middle and last phase per kernel.  Against the oracle's fftConvRef restatement."""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", str(cus))
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    n, batch = 1 << 20, 2
+    kn = (ks or [n])[0]
+    x = oracle.random_complex_interleaved(n * batch, 0xC4DE)
+    kern = oracle.random_complex_interleaved(kn * K, 0xC5DE)
+    desc, _ = _desc({"type": "fftconv", "shape": [n], "batch": batch,
+                     "fftConv": {"mode": mode, "boundary": "circular", "kernelCount": K, "kernelShape": ks, "outputLayout": layout}})
+    per = [oracle.fftconv_ref(x, kern[2 * k * kn:2 * (k + 1) * kn], [n], batch, mode, "circular", ks, use_pow2=True)[0].reshape(batch, 2 * n) for k in range(K)]
+    want = (np.concatenate(per) if layout == "kernel-major" else np.stack(per, axis=1)).reshape(-1)
+    got, route, launches = emu.run_plan(desc, x, want.size, kernel=kern)
+    assert "fftconv-pipeline[N=1024x1024,K=%d]" % K in route, route
+    _close(got, want, 4e-3, 4e-3, route)
+    assert oracle.rel_l2(got, want) < 1e-5, route
+
+
 def test_fftconv_fused_route_gives_way_to_line_kernels_at_throughput_sizes(oracle, monkeypatch):
     """the one-launch fftconv kernel is the latency route; above conv_fused_max_points the forward-mul + inverse line launches take
     over (same results)"""

@@ -596,6 +596,31 @@ def test_fftconv_product_fused_into_forward_lines(fft, dev, oracle, monkeypatch,
     assert oracle.rel_l2(got, old) < 1e-6
 
 
+@pytest.mark.parametrize("ks,mode,K,layout,batch", [(None, "convolution", 1, "kernel-major", 37), ([1000], "correlation", 3, "batch-major", 5)])
+def test_fftconv_pipeline_2p20(fft, dev, oracle, monkeypatch, ks, mode, K, layout, batch):
+    """2^20-point circular lines: forward transform, products and inverse transforms in ONE persistent launch (kern_regtile.hpp
+    fft_xcd_conv1m_kernel; more data lines than groups, K = 3 re-runs the middle and last phase per kernel); against the oracle's
+    fftConvRef restatement and against the forward + pointwise + inverse route (MI355FFT_CONV_PIPELINE=0)"""
+    n = 1 << 20
+    kn = (ks or [n])[0]
+    x = oracle.random_complex_interleaved(n * batch, 0xC4DE)
+    kern = oracle.random_complex_interleaved(kn * K, 0xC5DE)
+    opts = {"type": "fftconv", "shape": [n], "batch": batch, "fftConv": {"mode": mode, "boundary": "circular", "kernelCount": K, "kernelShape": ks, "outputLayout": layout}}
+    kernels = [kern[2 * k * kn:2 * (k + 1) * kn] for k in range(K)]
+    got, (route, _) = run_plan(fft, dev, opts, x, 2 * n * batch * K, kernel=kernels)
+    assert "fftconv-pipeline[N=1024x1024,K=%d]" % K in route, route
+    nb = min(batch, 3)                     # the oracle on the first data lines ...
+    per = [oracle.fftconv_ref(x[:2 * n * nb], kernels[k], [n], nb, mode, "circular", ks, use_pow2=True)[0].reshape(nb, 2 * n) for k in range(K)]
+    g = got.reshape(K, batch, 2 * n) if layout == "kernel-major" else got.reshape(batch, K, 2 * n).transpose(1, 0, 2)
+    for k in range(K):
+        check(oracle, g[k, :nb].reshape(-1), per[k].reshape(-1), f"{route.strip()} kernel {k}", 4e-3, 4e-3)
+        assert oracle.rel_l2(g[k, :nb].reshape(-1), per[k].reshape(-1)) < 1e-5, route
+    monkeypatch.setenv("MI355FFT_CONV_PIPELINE", "0")   # ... and every line against the composed route
+    old, (route0, _) = run_plan(fft, dev, opts, x, 2 * n * batch * K, kernel=kernels)
+    assert "fftconv-pipeline" not in route0, route0
+    assert oracle.rel_l2(got, old) < 1e-6
+
+
 def test_fftconv_cfg4_channel_lane_preset(fft, dev, oracle, manifest):
     """BASELINE config 4 with sentinel preservation (mirror of complete.suite.js:4812-4830)"""
     cases, _ = manifest

@@ -791,4 +791,178 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
   }
 }
 
+// ---- fftconv of 2^20-point lines as ONE pipeline (r03; src/runtime/plans/fftconv.js:1659-1706: forward -> pointwise -> inverse) ---------
+// y_k = IFFT(FFT(x) * H_k) / N, circular, dense lines, K kernel spectra H_k (transformed once per exec by the ordinary route).
+// The forward four-step's pass B produces the spectrum tile of rows k1 = 32 tile .. +31 in the registers of the consumer threads
+// (k2 = j2 + 32 q) — which IS the input of the inverse transform's pass A for the 32 columns n2 = k1 (input index k = k2 N1 + k1): same
+// thread, same registers.  So the spectrum never travels: per data line
+//   A    column FFTs of x -> W                                                        (16 B/point)
+//   M_k  rows of W, four-step roots, row FFT = spectrum tile; times H_k (transposed read); inverse pass A -> W2   (24 B/point)
+//   C_k  rows of W2, inverse four-step roots, row FFT, transposed store of y_k / N      (16 B/point)
+// = 56 B/point for one kernel where forward, pointwise and inverse launches move 88 (and 40 instead of 56 for every further kernel).
+// Inverse passes run the forward arithmetic on re/im-swapped data (radix.hpp): the product is swapped before M_k's second half, the
+// result swapped back at C_k's store.  Group barriers: A | M_k, M_k | C_k, and C_k | M_k+1 when another kernel follows (W2 is reused).
+template <int N1_>
+__global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_conv1m_kernel(const XcdFusedArgs f) {
+  static_assert(N1_ == 1024, "1024 x 1024");
+  MI_SMEM_DECL(smem);
+  cf* xb = reinterpret_cast<cf*>(smem);
+  cf* tw1 = xb + Rt1kCfg::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + Rt1kCfg::TW1_ELEMS);
+  const int t = threadIdx.x;
+  for (int i = t; i < Rt1kCfg::TW1_ELEMS; i += Rt1kCfg::THREADS) tw1[i] = f.tw_a[i];
+  if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
+  const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
+  constexpr unsigned N1 = 1024, N2 = 1024, NT = 32;
+  cf* const Wg = f.wslots + (size_t)(2u * (f.slots ? f.slots : 1u) * gslot) * (size_t)f.N;     // per group and line of a round: W and W2
+  const int cl = t & 31, h = t >> 5;        // column-side map
+  const int rl = t >> 4, hh = t & 15;       // row-side map
+  const bool first = MI_UNIFORM_U32((unsigned)t >> 8) == 0u;   // 16-row tiles of phase M: consumers ku = t div 16 < 16 are served in the first exchange half
+  const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
+  const auto stage1 = [&](cf (&w)[32], int j2) {
+    int ti = j2; MI_OPAQUE_LANE_INT(ti);
+#pragma unroll
+    for (int q = 1; q < 32; ++q) w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]);
+    fft_radix<32>(w);
+  };
+  // rows k1 = 32 tile + rl of a workspace slot, times the four-step roots e^{-2 pi i k1 n2/N}: this thread's elements n2 = 2hh (+1) + 32 q
+  const auto load_rows = [&](cf (&va)[32], cf (&vb)[32], const cf* S, unsigned tile) {
+    const unsigned k1 = tile * 32u + (unsigned)rl;
+    const cf* p = S + (size_t)(tile * 32u) * N2;
+    const unsigned lo = (unsigned)rl * N2 + 2u * (unsigned)hh;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const cf4 pr = *reinterpret_cast<const cf4*>(sgpr_base(p + 32 * q) + lo);
+      va[q] = cf{pr.x, pr.y}; vb[q] = cf{pr.z, pr.w};
+    }
+    const cf step = root(k1 * 32u), one = root(k1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      cf ra = root(k1 * (unsigned)(2 * hh + 256 * g));
+      cf rb = cmul(ra, one);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        va[8 * g + j] = cmul(va[8 * g + j], ra); vb[8 * g + j] = cmul(vb[8 * g + j], rb);
+        if (j < 7) { ra = cmul(ra, step); rb = cmul(rb, step); }
+      }
+    }
+  };
+  unsigned bar = 0;                                  // barriers passed so far (the counter is monotonic)
+  const auto group_barrier = [&]() -> bool {
+    xcd_arrive(&f.ctl->bar[gslot][0]);
+    ++bar;
+    return xcd_wait(&f.ctl->bar[gslot][0], bar * gsize, f.spin_limit, f.sticky_error, &s_words[6]);
+  };
+  // A round = L = f.slots data lines per group (2 L workspace slots): with one line per round a workgroup of a 32-strong group has one
+  // or two tiles per phase and the phases are pure latency; L lines give every phase L times the tiles between the same barriers.
+  const unsigned L = f.slots ? f.slots : 1u;
+  for (long long tr0 = (long long)gidx * L; tr0 < f.num_transforms; tr0 += (long long)groups * L) {
+    const unsigned nl = (unsigned)(f.num_transforms - tr0 < (long long)L ? f.num_transforms - tr0 : (long long)L);
+    // ---- A: 32 adjacent columns of x per tile -> W ----
+    for (unsigned tt = rank; tt < NT * nl; tt += gsize) {
+      const unsigned ll = tt / NT, tile = tt - ll * NT;
+      const cf* const x = f.in + (tr0 + ll) * f.in_pitch;
+      cf* const W = Wg + (size_t)(2u * ll) * (size_t)f.N;
+      cf va[32], vb[32], w[32];
+      {
+        const cf* p = x + tile * 32u;
+        const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+          va[q] = ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff);
+          vb[q] = ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff);
+        }
+      }
+      fft_radix<32>(va);
+      fft_radix<32>(vb);
+      cf* const po = W + tile * 32u;
+      const unsigned so = (unsigned)h * N2 + (unsigned)cl;
+      rt1k_exchange(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
+        stage1(w, h);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) *(sgpr_base(po + (unsigned)(32 * q) * N2) + so) = w[q];
+      });
+      stage1(w, h + 16);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) *(sgpr_base(po + (unsigned)(32 * q + 16) * N2) + so) = w[q];
+      __syncthreads();
+    }
+    if (!group_barrier()) return;
+    for (unsigned kk = 0; kk < f.conv_k; ++kk) {
+      const cf* const H = f.mul + (size_t)kk * (size_t)f.N;
+      // ---- M_k: spectrum tile of 16 rows k1, product, inverse pass A -> W2 ----
+      // (16-row tiles with ONE butterfly per thread — the exchange of fft_xcd_hx_kernel: a thread never holds more than its 32 values plus
+      // the 32 arriving ones.  The 32-row form, two butterflies per thread, keeps consumer 0's 32 results alive across consumer 1's stage
+      // and spilled 760 bytes per lane: 63 vs 70 GPoints/s for the three-launch route, profiles/r03_fftconv_pipeline_ab.log.)
+      for (unsigned tt = rank; tt < 2 * NT * nl; tt += gsize) {
+        const unsigned ll = tt / (2 * NT), tile = tt - ll * (2 * NT);
+        const cf* const W = Wg + (size_t)(2u * ll) * (size_t)f.N;
+        cf* const W2 = Wg + (size_t)(2u * ll + 1u) * (size_t)f.N;
+        const int ml = t >> 5, mu = t & 31;          // row-side map of a 16-row tile: row ml, elements n2 = mu + 32 q
+        const int kl = t & 15, ku = t >> 4;          // column-side map: row k1 = 16 tile + kl, butterfly ku
+        cf v[32], w[32];
+        {
+          const unsigned k1 = tile * 16u + (unsigned)ml;
+          const cf* p = W + (size_t)(tile * 16u) * N2;
+          const unsigned lo = (unsigned)ml * N2 + (unsigned)mu;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) v[q] = *(sgpr_base(p + 32 * q) + lo);
+          const cf step = root(k1 * 32u);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            cf r = root(k1 * (unsigned)(mu + 256 * g));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[8 * g + j] = cmul(v[8 * g + j], r); if (j < 7) r = cmul(r, step); }
+          }
+        }
+        fft_radix<32>(v);
+        hx_exchange(v, w, xb, ml, mu, kl, ku, first);
+        stage1(w, ku);
+        // w[q] = X[k1 + N1 (ku + 32 q)], k1 = 16 tile + kl: times H_k (conjugated for correlation), re/im swapped = the inverse transform's
+        // forward-arithmetic input of column n2 = k1, butterfly u = ku
+        {
+          const cf* ph = H + tile * 16u;
+          const unsigned ho = (unsigned)ku * N1 + (unsigned)kl;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const cf hq = *(sgpr_base(ph + (unsigned)(32 * q) * N1) + ho);
+            const cf pq = f.conv_conj ? cmul_conj(w[q], hq) : cmul(w[q], hq);
+            v[q] = pq.yx;
+          }
+        }
+        fft_radix<32>(v);
+        hx_exchange(v, w, xb, kl, ku, kl, ku, first);
+        stage1(w, ku);
+        cf* const po = W2 + tile * 16u;
+        const unsigned so = (unsigned)ku * N2 + (unsigned)kl;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) *(sgpr_base(po + (unsigned)(32 * q) * N2) + so) = w[q];
+      }
+      if (!group_barrier()) return;
+      // ---- C_k: rows of W2, roots, row FFT, transposed store of y_k (swapped back, times 1/N) ----
+      for (unsigned tt = rank; tt < NT * nl; tt += gsize) {
+        const unsigned ll = tt / NT, tile = tt - ll * NT;
+        cf* const y = f.out + (tr0 + ll) * f.out_pitch + (long long)kk * f.out_kernel_pitch;
+        const cf* const W2 = Wg + (size_t)(2u * ll + 1u) * (size_t)f.N;
+        cf va[32], vb[32], w[32];
+        load_rows(va, vb, W2, tile);
+        fft_radix<32>(va);
+        fft_radix<32>(vb);
+        cf* const po = y + tile * 32u;
+        const unsigned so = (unsigned)h * N1 + (unsigned)cl;
+        const auto store = [&](cf (&ww)[32], unsigned off) {
+#pragma unroll
+          for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, (ww[q] * f.scale).yx);
+        };
+        rt1k_exchange(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] { stage1(w, h); store(w, 0u); });
+        stage1(w, h + 16);
+        store(w, 16u);
+        __syncthreads();
+      }
+      // W2 is rewritten by M_k+1 (a further kernel, which passes no other barrier first); the next data line's M_0 comes after its A | M barrier
+      if (kk + 1 < f.conv_k) { if (!group_barrier()) return; }
+    }
+  }
+}
+
 }  // namespace mi355

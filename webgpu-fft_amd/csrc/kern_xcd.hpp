@@ -74,6 +74,10 @@ struct XcdFusedArgs {
   unsigned slots;                // workspace slots per group: 2 (one barrier per transform) or 1 (two barriers, half the footprint)
   unsigned solo;                 // 1: every workgroup is its own group (transforms of <= 1 MiB): no registration, no cross-
                                  // workgroup barrier, no co-residency requirement — the grid may be any size, one slot per workgroup
+  // fftconv pipeline (kern_regtile.hpp fft_xcd_conv1m_kernel): K kernel spectra of N points each, back to back
+  const cf* mul;
+  unsigned conv_k, conv_conj;    // kernels per data line; 1: correlation (conjugated spectra)
+  long long out_kernel_pitch;    // complex elements between the outputs of consecutive kernels of one data line (out_pitch: between data lines)
 };
 
 // roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by
@@ -132,10 +136,13 @@ MI_DEV void xcd_local_handoff() {
   __syncthreads();
   MI_ACQUIRE_AGENT();
 }
+#ifndef MI355_EXP_NO_WAIT
+#define MI355_EXP_NO_WAIT 0   /* timing-only builds: the group barriers do not wait (results wrong by construction): bounds what the waits cost */
+#endif
 MI_DEV bool xcd_wait(unsigned* counter, unsigned target, unsigned spin_limit, unsigned* sticky, unsigned* s_flag) {
   if (threadIdx.x == 0) {
-    unsigned ok = 0;
-    for (unsigned it = 0; it < spin_limit; ++it) {
+    unsigned ok = MI355_EXP_NO_WAIT;
+    for (unsigned it = 0; it < spin_limit && !MI355_EXP_NO_WAIT; ++it) {
       if (MI_ATOMIC_LOAD_U32(counter) >= target) { ok = 1; break; }
       MI_SLEEP();
     }

@@ -136,6 +136,7 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 on 32-line register tiles (fft_xcd_rt1k_kernel): rt = 3
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 0, 3}; r.push_back(m);
     }
+    { XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, false, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 4, 3}; r.push_back(m); }   // real = 4: fftconv pipeline for 2^20 points (fft_xcd_conv1m_kernel)
     return r;
   }();
   return reg;
@@ -170,6 +171,7 @@ PlannerOptions planner_options_from_env() {
   if (const char* s = std::getenv("MI355FFT_XCD_2D")) o.xcd_2d = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_RT")) o.xcd_rt = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_XCD_HX")) o.xcd_hx = std::atoi(s);
+  if (const char* s = std::getenv("MI355FFT_CONV_PIPELINE")) o.conv_pipeline = std::atoi(s);
   if (const char* s = std::getenv("MI355FFT_SOLO_MAX_KB")) { const int v = std::atoi(s); if (v >= 0) o.solo_max_kb = v; }
   if (const char* s = std::getenv("MI355FFT_SOLO_CAP_MB")) { const int v = std::atoi(s); if (v >= 1) o.solo_cap_mb = v; }
   if (const char* s = std::getenv("MI355FFT_XCD_SLOTS")) { const int v = std::atoi(s); if (v >= 0 && v <= 2) o.xcd_slots = v; }
@@ -1689,6 +1691,39 @@ int build_fftconv(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     rc = b.emit_nd(kernel_embed ? kf : kern, kf, fs, rank, K, false, 1.0f, err);
   }
   if (rc) return rc;
+  // 1b. 2^20-point circular lines, dense on both sides: forward transform, K products and K inverse transforms in ONE persistent launch
+  // whose spectrum tiles never leave the registers (kern_regtile.hpp fft_xcd_conv1m_kernel): 56 + 40 (K - 1) B/point instead of 88 + 56 (K - 1)
+  if (b.opt.conv_pipeline && !b.opt.force_generic && b.opt.xcd_fused == 1 && b.opt.xcd_shared && !b.opt.only_pass && rank == 1 && fN == ((int64_t)1 << 20) &&
+      d.conv_boundary == MI355FFT_CIRCULAR && !zpad && !d.input.strided && !d.output.strided) {
+    const XcdKernelMeta* xm = nullptr;
+    for (const auto& m : xcd_kernel_registry()) if (m.real == 4) xm = &m;
+    if (xm) {
+      // groups per XCD x data lines per round (two slots per line, W and W2), same box, GPoints/s (profiles/r03_fftconv_pipeline_ab.log):
+      // 2 x 1 101-104 (8 x 2 x 2 x 8 MiB = the Infinity Cache), 1 x 2 95-97, 2 x 2 92-96, 1 x 1 87-89, 4 x 1 68; three launches 70-73
+      const int64_t split = b.opt.xcd_split > 0 ? b.opt.xcd_split : 2;
+      const int64_t L = b.opt.xcd_slots > 0 ? b.opt.xcd_slots : 1;
+      const PtrRef wslots = b.alloc_work((uint64_t)(16 * 2 * L * split) * fN * 8), ctl = b.alloc_work(40960);
+      std::vector<float2h> lo(1024), hi((size_t)(fN >> 10));
+      for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, fN);
+      for (int64_t h = 0; h < (fN >> 10); ++h) hi[(size_t)h] = root_of_unity(h << 10, fN);
+      const LineKernelMeta ml = make_meta(0, 1024, 32, 32, 1, 32, true, true, false, false, 0);
+      const PtrRef ta = b.line_tables(ml), tlo = b.add_table(lo), thi = b.add_table(hi);
+      { Step& z = b.push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
+      Step& st = b.push(ST_XCD_FUSED);
+      st.variant = xm->id;
+      st.p[0] = in; st.p[1] = out; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+      st.i[0] = B; st.i[1] = fN; st.i[2] = 10; st.i[3] = 1023; st.i[9] = fN;
+      const bool kmajor = d.conv_output_layout == MI355FFT_KERNEL_MAJOR;
+      st.i[10] = kmajor ? oN : K * oN;        // between data lines
+      st.i[17] = kmajor ? B * oN : oN;        // between the kernels of one data line
+      st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = L; st.i[12] = 0; st.i[13] = b.opt.xcd_spin_limit;
+      st.i[14] = kf.off - wslots.off; st.i[15] = K; st.i[16] = d.conv_mode == MI355FFT_CORRELATION ? 1 : 0;
+      st.f[0] = (float)(1.0 / (double)fN);
+      st.grid = (unsigned)b.opt.compute_units;
+      b.ir.route += "fftconv-pipeline[N=1024x1024,K=" + std::to_string(K) + "] ";
+      return MI355FFT_OK;
+    }
+  }
   // 2. data: gather (strided lanes) / embed (linear modes) into the dense FFT domain, forward transform once
   PtrRef xf = b.alloc_work((uint64_t)B * fN * 8);
   const bool side_in = embed || d.input.strided || d.zero_read.enabled;

@@ -86,7 +86,7 @@ const std::vector<MixedCtMeta>& mixedct_registry();
 // registers (128-byte segments where the LDS-resident 8-line tiles above move 64-byte ones); forward and inverse.  Listed AFTER
 // the LDS-resident instances of the same size so that a registry walk finds them last (PlannerOptions::xcd_rt).
 #define MI355_XCD_RT_KERNEL_LIST(X) X(1024) X(2048)
-struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; int rt; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c; rt: 1 register-tile instance (2048-point sides), 2 the two-workgroups-per-CU 1024 x 1024
+struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; int rt; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c, 4 fftconv pipeline; rt: 1 register-tile instance (2048-point sides), 2 the two-workgroups-per-CU 1024 x 1024
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
 
@@ -172,6 +172,7 @@ struct PlannerOptions {
   int mixed_lds_kb = 0;                // experiments: LDS per workgroup of the mixed-radix line kernel (0 = per-length rule)
   int mixed_threads = 256;
   int64_t conv_fused_max_points = (int64_t)1 << 20;   // fftconv-fused (one launch, latency route) up to this many points B*N*K; above: forward-mul + inverse line launches
+  int conv_pipeline = 1;               // fftconv of 2^20-point circular dense lines: forward, products and inverses in one persistent launch (kern_regtile.hpp fft_xcd_conv1m_kernel)
   int conv_lines = 1;                  // fftconv: kernel-spectrum product fused behind the forward line FFT (1-D, power-of-two FFT length <= max_line)
   int trig_fused = 1;                  // dct2 / dst2 of dense lines (half length a line-kernel size): permutation + real FFT + phase in one launch
   int trig_real = 1;                   // dct2/dst2/dct3/dst3 along a dense even axis through a real FFT of length N (kern_trig.hpp)
