@@ -656,6 +656,12 @@ __global__ void __launch_bounds__(HxCfg::THREADS, MI355_HX_WAVES) fft_xcd_hx_ker
 #ifndef MI355_RT1K_NT_IN
 #define MI355_RT1K_NT_IN MI355_RT_NT_IN
 #endif
+#ifndef MI355_RT1K_TW_FENCE
+#define MI355_RT1K_TW_FENCE 8
+#endif
+#ifndef MI355_RT1K_PREFETCH
+#define MI355_RT1K_PREFETCH 0    /* loads per thread (of 64) requested one tile ahead: 0, 8, 16, 32.  32: 276 B of scratch, 174.5 vs 196.4 GPoints/s (profiles/r03_headline_rt32_ab.log) */
+#endif
 #ifndef MI355_RT1K_W_NT
 #define MI355_RT1K_W_NT 0      /* experiment: nontemporal accesses to the intermediate */
 #endif
@@ -707,82 +713,108 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
   const auto stage1 = [&](cf (&w)[32], int j2) {
     int ti = j2; MI_OPAQUE_LANE_INT(ti);     // (not loop-invariant for the optimiser: hoisted, the 31 roots would pin 62 registers)
 #pragma unroll
-    for (int q = 1; q < 32; ++q) w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]);
+    for (int q = 1; q < 32; ++q) {
+      w[q] = cmul(w[q], tw1[(q - 1) * 32 + ti]);
+      if (MI355_RT1K_TW_FENCE && q % MI355_RT1K_TW_FENCE == 0) MI_SCHED_FENCE();   // at most this many roots in flight (registers) at a time
+    }
     fft_radix<32>(w);
   };
   unsigned k = 0;
   for (long long tr = gidx; tr < f.num_transforms; tr += groups, ++k) {
     cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * (size_t)f.N;
     const cf* const x = f.in + tr * f.in_pitch;
+    // Software pipeline over a workgroup's tiles (MI355_RT1K_PREFETCH = P, experiment): P of the next tile's 64 loads per thread are requested
+    // as soon as the second exchange half has left the registers that held this tile, i.e. they are in flight while both consumers'
+    // stage 1 computes and stores; the rest follows at the top of the next iteration.  Off by default: the registers they pin cost more
+    // (spills) than the overlap gains.
     // ---- phase A: 32 adjacent columns per tile ----
-    for (unsigned tile = rank; tile < NT; tile += gsize) {
+    {
       cf va[32], vb[32], w[32];
-      {
+      const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
+      constexpr int PF = MI355_RT1K_PREFETCH;     // how many of va's 32 loads are requested one tile ahead
+      const auto load_a = [&](unsigned tile, int q0, int q1) {
         const cf* p = x + tile * 32u;
-        const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          va[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
-          vb[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff));
-        }
+        for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) va[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
+      };
+      const auto load_b = [&](unsigned tile) {
+        const cf* p = x + tile * 32u;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) vb[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff));
+      };
+      if (PF && rank < NT) load_a(rank, 0, PF);
+      for (unsigned tile = rank; tile < NT; tile += gsize) {
+        load_a(tile, PF, 32);
+        load_b(tile);
+        fft_radix<32>(va);
+        fft_radix<32>(vb);
+        cf* const po = W + tile * 32u;
+        const unsigned so = (unsigned)h * N2 + (unsigned)cl;
+        rt1k_exchange(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
+          if (PF && tile + gsize < NT) load_a(tile + gsize, 0, PF);
+          stage1(w, h);
+#pragma unroll
+          for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q) * N2) + so, w[q]);
+        });
+        stage1(w, h + 16);
+#pragma unroll
+        for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q + 16) * N2) + so, w[q]);
+        __syncthreads();
       }
-      fft_radix<32>(va);
-      fft_radix<32>(vb);
-      cf* const po = W + tile * 32u;
-      const unsigned so = (unsigned)h * N2 + (unsigned)cl;
-      rt1k_exchange(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
-        stage1(w, h);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q) * N2) + so, w[q]);
-      });
-      stage1(w, h + 16);
-#pragma unroll
-      for (int q = 0; q < 32; ++q) st_stream<MI355_RT1K_W_NT != 0>(sgpr_base(po + (unsigned)(32 * q + 16) * N2) + so, w[q]);
-      __syncthreads();
     }
     xcd_arrive(&f.ctl->bar[gslot][0]);
     if (!xcd_wait(&f.ctl->bar[gslot][0], (k + 1u) * gsize, f.spin_limit, f.sticky_error, &s_words[6])) return;
     // ---- phase B: 32 adjacent rows per tile, four-step roots on load, transposed store ----
     cf* const y = f.out + tr * f.out_pitch;
-    for (unsigned tile = rank; tile < NT; tile += gsize) {
+    {
       cf va[32], vb[32], w[32];
-      {
-        const unsigned k1 = tile * 32u + (unsigned)rl;
+      const unsigned lo = (unsigned)rl * N2 + 2u * (unsigned)hh;
+      constexpr int PF = MI355_RT1K_PREFETCH / 2;  // how many of the 32 16-byte loads are requested one tile ahead
+      const auto load_rows = [&](unsigned tile, int q0, int q1) {      // elements 2hh + 32q and 2hh + 1 + 32q of row 32 tile + rl, q = q0 .. q1 - 1
         const cf* p = W + (size_t)(tile * 32u) * N2;
-        const unsigned lo = (unsigned)rl * N2 + 2u * (unsigned)hh;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          const cf4 pr = *reinterpret_cast<const cf4*>(sgpr_base(p + 32 * q) + lo);     // elements 2hh + 32q and 2hh + 1 + 32q of row k1
+        for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) {
+          const cf4 pr = *reinterpret_cast<const cf4*>(sgpr_base(p + 32 * q) + lo);
           va[q] = cf{pr.x, pr.y}; vb[q] = cf{pr.z, pr.w};
         }
-        const cf step = root(k1 * 32u), one = root(k1);
+      };
+      if (PF && rank < NT) load_rows(rank, 0, PF);
+      for (unsigned tile = rank; tile < NT; tile += gsize) {
+        load_rows(tile, PF, 32);
+        {
+          const unsigned k1 = tile * 32u + (unsigned)rl;
+          const cf step = root(k1 * 32u), one = root(k1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          cf ra = root(k1 * (unsigned)(2 * hh + 256 * g));
-          cf rb = cmul(ra, one);
+          for (int g = 0; g < 4; ++g) {
+            cf ra = root(k1 * (unsigned)(2 * hh + 256 * g));
+            cf rb = cmul(ra, one);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            va[8 * g + j] = cmul(va[8 * g + j], ra); vb[8 * g + j] = cmul(vb[8 * g + j], rb);
-            if (j < 7) { ra = cmul(ra, step); rb = cmul(rb, step); }
+            for (int j = 0; j < 8; ++j) {
+              va[8 * g + j] = cmul(va[8 * g + j], ra); vb[8 * g + j] = cmul(vb[8 * g + j], rb);
+              if (j < 7) { ra = cmul(ra, step); rb = cmul(rb, step); }
+            }
           }
         }
-      }
-      fft_radix<32>(va);
-      fft_radix<32>(vb);
-      cf* const po = y + tile * 32u;
-      const unsigned so = (unsigned)h * N1 + (unsigned)cl;
-      const auto store = [&](cf (&ww)[32], unsigned off) {
+        fft_radix<32>(va);
+        fft_radix<32>(vb);
+        cf* const po = y + tile * 32u;
+        const unsigned so = (unsigned)h * N1 + (unsigned)cl;
+        const auto store = [&](cf (&ww)[32], unsigned off) {
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-          cf r = ww[q];
-          if (f.scale != 1.0f) r = r * f.scale;
-          st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
-        }
-      };
-      rt1k_exchange(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] { stage1(w, h); store(w, 0u); });
-      stage1(w, h + 16);
-      store(w, 16u);
-      __syncthreads();
+          for (int q = 0; q < 32; ++q) {
+            cf r = ww[q];
+            if (f.scale != 1.0f) r = r * f.scale;
+            st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
+          }
+        };
+        rt1k_exchange(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] {
+          if (PF && tile + gsize < NT) load_rows(tile + gsize, 0, PF);
+          stage1(w, h); store(w, 0u);
+        });
+        stage1(w, h + 16);
+        store(w, 16u);
+        __syncthreads();
+      }
     }
     if (!two_slots) {
       xcd_arrive(&f.ctl->bar[gslot][1]);
