@@ -256,6 +256,37 @@ def test_c2c_lane_layout_needs_no_staging(oracle):
         assert np.array_equal(got[:2 * out_off], sentinel[:2 * out_off])
 
 
+@pytest.mark.parametrize("lg,label", [(17, "xcd-fused[N=256x512]"), (20, "xcd-fused-rt32[N=1024x1024]")])
+def test_c2c_lane_layout_on_four_step_sizes(oracle, monkeypatch, lg, label):
+    """rank-1 lane layouts of four-step sizes (r03): the fused kernel takes the two pitches and the base offsets as they are — one
+    launch (+ its control-block reset), no gather / scatter; elements between the lanes keep their sentinel"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "3")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    n, batch = 1 << lg, 3
+    x = oracle.random_complex_batch(n, batch, 0x1A9F + lg).reshape(-1)
+    in_off, in_pitch, out_off, out_pitch = 7, n + 300, 3, 2 * n
+    phys = np.full(2 * (in_off + (batch - 1) * in_pitch + n), 9.0, np.float32)
+    for b in range(batch):
+        phys[2 * (in_off + b * in_pitch):2 * (in_off + b * in_pitch + n)] = x[2 * b * n:2 * (b + 1) * n]
+    out_elems = out_off + (batch - 1) * out_pitch + n
+    sentinel = np.tile(np.array([77.0, -55.0], np.float32), out_elems)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc = _abi.make_desc("c2c", [n], batch, direction, norm,
+                              input_layout={"strides": [1], "offset": in_off, "batch_stride": in_pitch},
+                              output_layout={"strides": [1], "offset": out_off, "batch_stride": out_pitch})
+        got, route, launches = emu.run_plan(desc, phys, 2 * out_elems, out_init=sentinel)
+        assert route.startswith(label) and "lanes[pitch=%d/%d]" % (in_pitch, out_pitch) in route and launches == 2, route
+        want = sentinel.copy()
+        ref = oracle.c2c_ref_batch(x, [n], batch, direction, norm)
+        for b in range(batch):
+            want[2 * (out_off + b * out_pitch):2 * (out_off + b * out_pitch + n)] = ref[2 * b * n:2 * (b + 1) * n]
+        check(got, want, f"lane layout 2^{lg} {direction}", 2e-6)
+        assert np.array_equal(got[:2 * out_off], sentinel[:2 * out_off])
+        gap = got[2 * (out_off + n):2 * (out_off + out_pitch)]
+        assert np.array_equal(gap, sentinel[2 * (out_off + n):2 * (out_off + out_pitch)])
+
+
 def test_c2c_generic_route_matches_lines_route(oracle):
     x = oracle.random_complex_batch(1024, 2, 3).reshape(-1)
     desc = _abi.make_desc("c2c", [1024], 2, "forward", "none")

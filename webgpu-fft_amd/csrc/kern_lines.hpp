@@ -778,6 +778,12 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 //
 // MAPPED (r02): the packed bins are read through a.imap (zeros outside its box) and the real line leaves the
 // LDS line buffer through a.omap (element = one float), as in the r2c kernel above.
+#ifndef MI355_C2R_PV_8K
+#define MI355_C2R_PV_8K 1
+#endif
+#ifndef MI355_C2R_PV_16K
+#define MI355_C2R_PV_16K 2
+#endif
 #ifndef MI355_C2R_PRE_VEC
 #define MI355_C2R_PRE_VEC 1
 #endif
@@ -822,7 +828,7 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
           // two adjacent bins per lane: X[k], X[k+1] and their mirrors X[H-k-1], X[H-k] arrive as two 16-byte loads (k odd; the last
           // item ends on the self-mirrored bin H/2; bins 0 / H are an item of their own), PV items' loads in flight at a time
           typedef float f4w __attribute__((ext_vector_type(4), aligned(8)));
-          constexpr int QP = H / 4, PERV = QP + 1, PV = H == 8192 ? 1 : 2;   // (H = 8192: 403 vs 266 G real points/s with 1 vs 2 items in flight; H = 16384: 346 vs 383)
+          constexpr int QP = H / 4, PERV = QP + 1, PV = H == 8192 ? MI355_C2R_PV_8K : (H == 16384 ? MI355_C2R_PV_16K : 2);   // (H = 8192: 403 vs 266 G real points/s with 1 vs 2 items in flight; H = 16384: 346 vs 383)
           const auto presplit = [&](cf pk, cf m, int k, cf wh, cf wl, cf* xl) {
             if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
             const cf w = cmul(wh, wl);

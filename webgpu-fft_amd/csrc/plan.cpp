@@ -230,6 +230,10 @@ struct Builder {
   PlanIR& ir;
   const PlannerOptions& opt;
   uint64_t work_top = 0;
+  // rank-1 lane layouts on the four-step sizes (build_c2c): the pitches between consecutive lines that the fused kernel of the next
+  // emit_axis should use instead of N; lane_used reports that a fused launch took them (any other route ignores them)
+  int64_t lane_in_pitch = 0, lane_out_pitch = 0;
+  bool lane_used = false;
   Builder(PlanIR& i, const PlannerOptions& o) : ir(i), opt(o) {}
 
   PtrRef alloc_work(uint64_t bytes) {
@@ -696,7 +700,9 @@ struct Builder {
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
         st.p[0] = src; st.p[1] = dst; st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
-        st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = N; st.i[10] = N;
+        st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1;
+        st.i[9] = lane_in_pitch ? lane_in_pitch : N; st.i[10] = lane_out_pitch ? lane_out_pitch : N;
+        if (lane_in_pitch || lane_out_pitch) lane_used = true;
         st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = solo ? 1 : 0; st.i[13] = opt.xcd_spin_limit;
         st.f[0] = scale;
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
@@ -1270,6 +1276,18 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
     if (ip >= n && op >= n && ip < ((int64_t)1 << 24) && op < ((int64_t)1 << 24) &&
         b.emit_lines_pitched(in.plus(ioff * 8), out.plus(ooff * 8), n, d.batch, inverse, scale, ip, op))
       return MI355FFT_OK;
+    // four-step sizes (r03): the fused kernels take the two pitches as they are — channel lanes and whdcn layouts of long lines need
+    // no gather / scatter either.  Any other route of emit_axis would ignore the pitches: it is rolled back and the staging path taken.
+    if (ip >= n && op >= n && n > b.opt.max_line && is_pow2(n) && b.opt.fuse_views && !b.opt.force_generic) {
+      const size_t mark = b.ir.steps.size();
+      const std::string route_mark = b.ir.route;
+      const uint64_t work_mark = b.work_top, work_bytes_mark = b.ir.work_bytes;
+      b.lane_in_pitch = ip; b.lane_out_pitch = op; b.lane_used = false;
+      const int rcl = b.emit_axis(in.plus(ioff * 8), out.plus(ooff * 8), n, 1, d.batch, inverse, scale, err);
+      b.lane_in_pitch = b.lane_out_pitch = 0;
+      if (rcl == MI355FFT_OK && b.lane_used) { b.ir.route += "lanes[pitch=" + std::to_string(ip) + "/" + std::to_string(op) + "] "; return MI355FFT_OK; }
+      b.ir.steps.resize(mark); b.ir.route = route_mark; b.work_top = work_mark; b.ir.work_bytes = work_bytes_mark; err.clear();
+    }
   }
 
   // ---- sides fused into the line kernels: where the first / last transformed axis runs as a line-kernel
