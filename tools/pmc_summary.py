@@ -24,7 +24,7 @@ def main():
     launches = json.loads(sys.argv[4])  # {kernel substring: launches per step}
     kernels, total = [], 0.0
     for name in fetch:
-        if not any(k in name for k in ("fft_lines_kernel", "fft_xcd_fused_kernel", "fft_xcd_res_kernel", "fft_line32k_kernel", "fft_line_reg_kernel", "stockham", "r2c_post", "c2r_pre", "fft_xcd_r2c", "fft_xcd_c2r", "fft_xcd_rt", "fft_xcd_hx")):
+        if not any(k in name for k in ("fft_lines_kernel", "fft_xcd_fused_kernel", "fft_xcd_res_kernel", "fft_line32k_kernel", "fft_line_reg_kernel", "stockham", "r2c_post", "c2r_pre", "fft_xcd_r2c", "fft_xcd_c2r", "fft_xcd_rt", "fft_xcd_hx", "fft_xcd_conv")):
             continue
         rd = fetch[name] * 1024 * 2.0      # gfx950 x2 read correction
         wr = write.get(name, 0.0) * 1024

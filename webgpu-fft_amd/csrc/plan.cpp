@@ -765,7 +765,7 @@ struct Builder {
     // dense lines of a length with a compile-time-plan instance (kern_mixed_ct.hpp)
     if (opt.mixed_lines && opt.mixed_ct && !opt.force_generic && S == 1) {
       const MixedCtMeta* cm = nullptr;
-      for (const auto& m : mixedct_registry()) if (m.N == N) cm = &m;
+      for (const auto& m : mixedct_registry()) if (m.N == N && (!cm || opt.mixed_ct != 2)) cm = &m;
       if (cm) {
         std::vector<float2h> t;
         Step& st = push(ST_LINES_MIXED);

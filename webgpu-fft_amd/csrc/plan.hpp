@@ -45,7 +45,11 @@ struct ConvKernelMeta { int id, N, R0, R1, TL; };
   X(3072, 2, 512, 16, 8, 8, 3) X(160, 16, 256, 8, 4, 5) X(320, 8, 256, 8, 8, 5) X(640, 4, 256, 8, 8, 2, 5) X(1280, 2, 256, 8, 8, 4, 5)  \
   X(2560, 1, 256, 8, 8, 8, 5) X(1000, 4, 256, 8, 5, 5, 5) X(2000, 4, 512, 16, 5, 5, 5) X(3000, 2, 512, 8, 5, 5, 5, 3)                   \
   X(105, 32, 256, 7, 5, 3) X(1001, 8, 512, 13, 11, 7) X(360, 8, 256, 8, 5, 3, 3) X(1920, 4, 512, 16, 8, 5, 3) X(2187, 1, 256, 3, 3, 3, 3, 3, 3, 3) \
-  X(500, 8, 256, 4, 5, 5, 5) X(1500, 2, 256, 4, 5, 5, 5, 3) X(120, 32, 256, 8, 5, 3) X(240, 16, 256, 4, 4, 5, 3) X(480, 8, 256, 8, 4, 5, 3) X(720, 4, 256, 16, 5, 3, 3) X(1440, 2, 256, 8, 4, 5, 3, 3)
+  X(500, 8, 256, 4, 5, 5, 5) X(1500, 2, 256, 4, 5, 5, 5, 3) X(120, 32, 256, 8, 5, 3) X(240, 16, 256, 4, 4, 5, 3) X(480, 8, 256, 8, 4, 5, 3) X(720, 4, 256, 16, 5, 3, 3) X(1440, 2, 256, 8, 4, 5, 3, 3) \
+  /* r03: 2187 = 9*9*9*3 (radix 9 by direct evaluation with literal roots: 4 LDS passes instead of 7): 180 -> 194 GPoints/s.  Listed after the plan it \
+     replaces: the registry walk takes the last match (MI355FFT_MIXED_CT=2: the first).  3000 = 8*25*15 and 1500 = 4*25*15 measured SLOWER than their \
+     five-stage plans (168 vs 192, 145 vs 203: profiles/r03_mixed_radix_composite.log) and are not instantiated */ \
+  X(2187, 2, 512, 9, 9, 9, 3)
 
 struct MixedCtMeta { int id, N, T, threads, lds_bytes; std::vector<int> radices; };
 const std::vector<MixedCtMeta>& mixedct_registry();
