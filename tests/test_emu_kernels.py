@@ -430,6 +430,7 @@ def test_r2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
 @pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024"), (21, "1024x2048")])
 def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_XCD_RT", "0")          # 2^21: the LDS-resident instance (register tiles: test_r2c_xcd_regtile)
     monkeypatch.setenv("MI355_EMU_CUS", "4")
     monkeypatch.setenv("MI355_EMU_XCDS", "1")
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", "2")
@@ -442,8 +443,9 @@ def test_r2c_xcd_fused_product_sizes(oracle, monkeypatch, lg, label):
     check(got, want, f"xcd-r2c {label}", 1e-5)
 
 
-@pytest.mark.parametrize("cus,xcds,split,slots,norm", [(2, 2, 1, 2, "none"), (3, 1, 1, 1, "unitary"), (4, 1, 2, 2, "backward")])
-def test_r2c_xcd_regtile(oracle, monkeypatch, cus, xcds, split, slots, norm):
+@pytest.mark.parametrize("lg,label,cus,xcds,split,slots,norm", [(22, "2048x2048", 2, 2, 1, 2, "none"), (22, "2048x2048", 3, 1, 1, 1, "unitary"), (22, "2048x2048", 4, 1, 2, 2, "backward"),
+                                                                (21, "1024x2048", 3, 1, 0, 0, "none")])
+def test_r2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots, norm):
     """config 5's line (r2c N = 2^22) as a real four-step on register tiles (kern_regtile.hpp fft_xcd_rt_r2c_kernel): the
     separation of the two real columns of a complex column in the registers of the thread that owns both mirror consumers,
     65 row tiles (the last with one live row), Hermitian-mirrored stores incl. the Nyquist bin"""
@@ -452,13 +454,13 @@ def test_r2c_xcd_regtile(oracle, monkeypatch, cus, xcds, split, slots, norm):
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
     monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
-    n, batch = 1 << 22, 3
+    n, batch = 1 << lg, 3
     x = oracle.random_real_batch(n, batch, 0xD122 + cus).reshape(-1)
     want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm) for b in range(batch)])
     desc = _abi.make_desc("r2c", [n], batch, "forward", norm)
     got, route, launches = emu.run_plan(desc, x, batch * (n // 2 + 1) * 2)
-    assert route.startswith("xcd-r2c-rt[N=2048x2048]") and launches == 2, route
-    check(got, want, f"xcd-r2c-rt {norm}", 1e-5)
+    assert route.startswith(f"xcd-r2c-rt[N={label}]") and launches == 2, route
+    check(got, want, f"xcd-r2c-rt {label} {norm}", 1e-5)
 
 
 @pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (6, 3, 1, 1), (8, 2, 2, 2), (9, 1, 8, 2)])

@@ -499,7 +499,7 @@ def test_r2c_four_step_sizes(fft, dev, oracle, monkeypatch, lg, batch, fused):
     x = oracle.random_real_batch(n, batch, 0xE100 + lg).reshape(-1)
     for norm in ("none", "unitary"):
         got, (route, launches) = run_plan(fft, dev, {"type": "r2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": norm}, x, 2 * p * batch)
-        assert route.startswith("xcd-r2c-rt[" if lg == 22 else "xcd-r2c") == bool(fused), route   # 2^22 (r03): real four-step on register tiles (kern_regtile.hpp)
+        assert route.startswith("xcd-r2c-rt[" if lg >= 21 else "xcd-r2c") == bool(fused), route   # 2^21, 2^22 (r03): real four-step on register tiles (kern_regtile.hpp)
         want = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, norm, use_pow2=True) for b in range(batch)])
         check(oracle, got, want, f"r2c 2^{lg} {norm} ({route.strip()})", 8e-4, 8e-4)
 
@@ -697,6 +697,56 @@ def test_cfg2_full_size_properties(fft, dev, oracle):
 def test_cfg3_full_size_properties(fft, dev, oracle):
     """BASELINE config 3 (north-star metric): N=2^20 batch=4096 — 32 GiB per buffer"""
     _full_size_properties(fft, dev, oracle, 1 << 20, 4096, 0x5EED0003)
+
+
+@pytest.mark.parametrize("lg,batch", [(21, 1024), (22, 512)])
+def test_c2c_register_tile_sizes_full_size_properties(fft, dev, oracle, lg, batch):
+    """the register-tile instances (kern_regtile.hpp) at bench-sized batches — 16 GiB per buffer: every group walks 64-128 transforms"""
+    _full_size_properties(fft, dev, oracle, 1 << lg, batch, 0x5EED0021 + lg)
+
+
+def test_fftconv_pipeline_full_size_matches_composed_route(fft, dev, oracle, monkeypatch):
+    """fftconv of 2^20-point lines x 384 data lines, one full-length kernel: the one-launch pipeline against the forward + pointwise +
+    inverse route over the whole batch (device-side difference), plus conv(x, delta) = x as an absolute anchor"""
+    n, batch = 1 << 20, 384
+    x = dev.createBuffer({"size": n * batch * 8})
+    dev.fillRandom(x, 0, 2 * n, batch, 0x5EED0C01, 0)
+    kern = oracle.random_complex_interleaved(n, 0x5EED0C02)
+    opts = {"type": "fftconv", "shape": [n], "batch": batch, "fftConv": {"mode": "convolution", "boundary": "circular", "kernelCount": 1}}
+    outs = []
+    for pipeline in ("1", "0"):
+        monkeypatch.setenv("MI355FFT_CONV_PIPELINE", pipeline)
+        plan = fft.createPlan(dev, opts)
+        assert ("fftconv-pipeline" in plan.describe()[0]) == (pipeline == "1"), plan.describe()
+        y = dev.createBuffer({"size": n * batch * 8})
+        kb = fft.uploadComplex(dev, kern)
+        enc = dev.createCommandEncoder()
+        plan.exec(enc, {"input": x, "output": y, "kernel": kb})
+        dev.queue.submit([enc.finish()])
+        dev.queue.onSubmittedWorkDone()
+        outs.append(y)
+        plan.destroy()
+        kb.destroy()
+    e = dev.sumsq(outs[1], 0, 2 * n * batch)
+    d = dev.diffSumsq(outs[0], 0, outs[1], 0, 1.0, 2 * n * batch)
+    assert np.sqrt(d / e) < 1e-6, f"pipeline vs composed rel_l2={np.sqrt(d / e):.3e}"
+    # identity kernel: y = x
+    delta = np.zeros(2 * n, np.float32)
+    delta[0] = 1.0
+    monkeypatch.setenv("MI355FFT_CONV_PIPELINE", "1")
+    plan = fft.createPlan(dev, opts)
+    kb = fft.uploadComplex(dev, delta)
+    enc = dev.createCommandEncoder()
+    plan.exec(enc, {"input": x, "output": outs[0], "kernel": kb})
+    dev.queue.submit([enc.finish()])
+    dev.queue.onSubmittedWorkDone()
+    e_in = dev.sumsq(x, 0, 2 * n * batch)
+    d = dev.diffSumsq(outs[0], 0, x, 0, 1.0, 2 * n * batch)
+    assert np.sqrt(d / e_in) < 1e-5, f"conv with delta rel_l2={np.sqrt(d / e_in):.3e}"
+    plan.destroy()
+    kb.destroy()
+    for b in outs + [x]:
+        b.destroy()
 
 
 def test_cfg5_shard_full_size_properties(fft, dev, oracle):

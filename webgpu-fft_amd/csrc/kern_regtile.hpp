@@ -311,17 +311,24 @@ MI_DEV void rt_separate_store(cf* wt, unsigned k1, unsigned N2, cf a, cf b) {
 
 template <int N1_>     // (a template so that only the translation unit of its instance carries the device code)
 __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const XcdFusedArgs f) {
-  static_assert(N1_ == 2048, "2048 x 2048");
+  static_assert(N1_ == 2048 || N1_ == 1024, "2048 x 2048 (both passes on register tiles) or 1024 x 2048 (pass A on the LDS-resident 16 x 1024 tiles of kern_xcd_real.hpp)");
+  using XC = XcdRtCfg<N1_, false>;
+  using CA = typename XC::CA;
   MI_SMEM_DECL(smem);
   cf* xb = reinterpret_cast<cf*>(smem);
-  cf* tw2 = xb + RtCfg::HALF_ELEMS;
+  cf* tw_a = xb + XC::DATA;
+  cf* tw2 = tw_a + XC::TW_A;
   unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + RtCfg::TW2_ELEMS);
   const int t = threadIdx.x;
+  if constexpr (!XC::A_RT) { for (int i = t; i < XC::TW_A; i += RtCfg::THREADS) tw_a[i] = f.tw_a[i]; }
   for (int i = t; i < RtCfg::TW2_ELEMS; i += RtCfg::THREADS) tw2[i] = f.tw_b[i];
   if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
-  constexpr unsigned N1 = 2048, N2 = 2048, ROWS = N1 / 2 + 1, NREAL = N1 * N2;
+  constexpr unsigned N1 = N1_, N2 = 2048, ROWS = N1 / 2 + 1, NREAL = N1 * N2;
+  LineArgs aa{};
+  aa.tw = f.tw_a; aa.num_tiles = (N2 / 2) / 16; aa.num_lines = N2 / 2;
+  aa.in_S = N2 / 2; aa.in_outer_stride = NREAL / 2; aa.out_S = N2 / 2; aa.out_outer_stride = NREAL / 2; aa.scale = 1.0f; aa.fs_group = 1;
   constexpr size_t wsize = (size_t)ROWS * N2;
   const bool two_slots = f.slots != 1u;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * wsize;
@@ -330,6 +337,26 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
     cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * wsize;
     const cf* const x = f.in + tr * f.in_pitch;
     // ---- phase A ----
+    if constexpr (!XC::A_RT) {
+      // LDS-resident pass A (kern_xcd_real.hpp): 16 complex columns of length 1024, the finished columns kept in LDS, separation from there
+      aa.in = x; aa.out = W;
+      for (unsigned tile = rank; tile < (N2 / 2) / 16; tile += gsize) {
+        cf v[CA::E];
+        stage_read<CA, 0, RT_NT_IN>(v, aa, tile, t, xb);
+        stage_compute_write<CA, 0>(v, aa, tile, t, xb, tw_a, nullptr);
+        __syncthreads();
+        stage_read<CA, 1>(v, aa, tile, t, xb);
+        __syncthreads();
+        stage_compute_write<CA, 1, false, true>(v, aa, tile, t, xb, tw_a, nullptr);
+        __syncthreads();
+        cf* const wt = W + tile * 32u;
+        for (int p = t; p < (int)ROWS * 16; p += RtCfg::THREADS) {
+          const int k1 = p >> 4, c = p & 15;
+          rt_separate_store(wt + 2 * c, (unsigned)k1, N2, xb[k1 * 16 + c], xb[((N1 - k1) & (N1 - 1)) * 16 + c]);
+        }
+        __syncthreads();
+      }
+    } else
     for (unsigned tile = rank; tile < (MI355_RT_ONLY_PHASE == 2 ? 0u : (N2 / 2) / 16); tile += gsize) {
       const int line = t & 15, jj = t >> 4;
       cf v[64], v0[32], v1[32];
@@ -419,6 +446,7 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_r2c_kernel(const Xc
 struct XcdRtR2cCfg {
   static constexpr int THREADS = RtCfg::THREADS, LDS_BYTES = (RtCfg::HALF_ELEMS + RtCfg::TW2_ELEMS) * 8 + 64;
 };
+template <int N1_> struct XcdRtR2cCfgN { static constexpr int THREADS = RtCfg::THREADS, LDS_BYTES = XcdRtCfg<N1_, false>::LDS_BYTES; };
 
 // ---- c2r: the Hermitian four-step of kern_xcd_real.hpp on register tiles, N = 2048 x 2048 real samples -----------------------
 // x = IFFT(X) = FFT(conj X) for real x: a FORWARD four-step over Xt = conj(X_full), input index n1*N2 + n2 (bins), output

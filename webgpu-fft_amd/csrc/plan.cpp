@@ -137,6 +137,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 0, 3}; r.push_back(m);
     }
     { XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, false, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 4, 3}; r.push_back(m); }   // real = 4: fftconv pipeline for 2^20 points (fft_xcd_conv1m_kernel)
+    { const LineKernelMeta ma = make_meta(0, 1024, 32, 32, 1, 16, true, true, false, false, 0);   // r2c 1024 x 2048: LDS-resident pass A + register-tile pass B (fft_xcd_rt_r2c_kernel<1024>)
+      XcdKernelMeta m{id++, 1024, 2048, {32, 32, 1}, {64, 32, 1}, 16, 16, false, 512, 0, 1, 1};
+      m.lds_bytes = std::max(ma.lds_bytes - ma.tw_elems * 8, 16 * 32 * 32 * 8) + ma.tw_elems * 8 + 31 * 64 * 8 + 64; r.push_back(m); }
     return r;
   }();
   return reg;
@@ -397,7 +400,7 @@ struct Builder {
       wslots = alloc_work((uint64_t)grid * wsize * 8);
       ctl = alloc_work(256);
     } else {
-      xcd_groups((uint64_t)wsize * 8, xm->rt == 1, split, slots);
+      xcd_groups((uint64_t)wsize * 8, xm->rt == 1 && xm->N1 == 2048, split, slots);
       wslots = alloc_work((uint64_t)(16 * slots * split) * wsize * 8);
       ctl = alloc_work(40960);
     }
@@ -405,7 +408,7 @@ struct Builder {
     std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
     for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
     for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
-    const PtrRef tb = xm->rt ? regtile_table() : line_tables(mb), ta = xm->rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
+    const PtrRef tb = xm->rt ? regtile_table() : line_tables(mb), ta = (xm->rt && xm->N1 == 2048) ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
     if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
