@@ -485,8 +485,8 @@ def test_c2r_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
             check(got, x, "c2r(r2c(x)) = x", 1e-5)
 
 
-@pytest.mark.parametrize("cus,xcds,split,slots", [(2, 2, 1, 2), (3, 1, 1, 1)])
-def test_c2r_xcd_regtile(oracle, monkeypatch, cus, xcds, split, slots):
+@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(22, "2048x2048", 2, 2, 1, 2), (22, "2048x2048", 3, 1, 1, 1), (21, "1024x2048", 3, 1, 0, 0)])
+def test_c2r_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots):
     """c2r N = 2^22 as a Hermitian four-step on register tiles (kern_regtile.hpp fft_xcd_rt_c2r_kernel): 65 column tiles (the last
     with one live column), mirrored loads of the lower half columns, packed row pairs; against the signal and the oracle's c2r"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
@@ -494,13 +494,13 @@ def test_c2r_xcd_regtile(oracle, monkeypatch, cus, xcds, split, slots):
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
     monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
-    n, batch = 1 << 22, 3
+    n, batch = 1 << lg, 3
     x = oracle.random_real_batch(n, batch, 0xD322 + cus).reshape(-1)
     spec = np.concatenate([oracle.r2c_ref_packed(x[b * n:(b + 1) * n], n, "none") for b in range(batch)])
     desc = _abi.make_desc("c2r", [n], batch, "inverse", "backward")
     got, route, launches = emu.run_plan(desc, spec, n * batch)
-    assert route.startswith("xcd-c2r-rt[N=2048x2048]") and launches == 2, route
-    check(got, x, "xcd-c2r-rt", 1e-5)
+    assert route.startswith(f"xcd-c2r-rt[N={label}]") and launches == 2, route
+    check(got, x, f"xcd-c2r-rt {label}", 1e-5)
 
 
 @pytest.mark.parametrize("lg,label", [(18, "512x512"), (19, "512x1024"), (20, "1024x1024")])

@@ -463,17 +463,23 @@ template <int N1_> struct XcdRtR2cCfgN { static constexpr int THREADS = RtCfg::T
 //          the output, i.e. the transposed store of the c2c pass B with N1/2 complex rows writes the real line directly.
 template <int N1_>
 __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_c2r_kernel(const XcdFusedArgs f) {
-  static_assert(N1_ == 2048, "2048 x 2048");
+  static_assert(N1_ == 2048 || N1_ == 1024, "2048 x 2048, or 1024 x 2048 with pass A on LDS-resident 16 x 1024 tiles (the packing then walks the LDS image)");
+  using XC = XcdRtCfg<N1_, false>;
+  using CA = typename XC::CA;
   MI_SMEM_DECL(smem);
   cf* xb = reinterpret_cast<cf*>(smem);
-  cf* tw2 = xb + RtCfg::HALF_ELEMS;
+  cf* tw_a = xb + XC::DATA;
+  cf* tw2 = tw_a + XC::TW_A;
   unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + RtCfg::TW2_ELEMS);
   const int t = threadIdx.x;
+  if constexpr (!XC::A_RT) { for (int i = t; i < XC::TW_A; i += RtCfg::THREADS) tw_a[i] = f.tw_a[i]; }
   for (int i = t; i < RtCfg::TW2_ELEMS; i += RtCfg::THREADS) tw2[i] = f.tw_b[i];
   if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
 
-  constexpr int N1 = 2048, N2 = 2048, COLS = N2 / 2 + 1;
+  constexpr int N1 = N1_, N2 = 2048, COLS = N2 / 2 + 1;
+  LineArgs aa{};
+  aa.tw = f.tw_a; aa.num_tiles = (COLS + 15) / 16; aa.num_lines = COLS; aa.out_S = 16; aa.out_outer_stride = 0; aa.scale = 1.0f; aa.fs_group = 1;
   constexpr size_t wsize = (size_t)(N1 / 2) * N2;
   const bool two_slots = f.slots != 1u;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * wsize;
@@ -483,6 +489,40 @@ __global__ void __launch_bounds__(RtCfg::THREADS) fft_xcd_rt_c2r_kernel(const Xc
     cf* const W = W0 + (size_t)(two_slots ? (k & 1u) : 0u) * wsize;
     const cf* const X = f.in + tr * f.in_pitch;
     // ---- phase A ----
+    if constexpr (!XC::A_RT) {
+      for (unsigned tile = rank; tile < (COLS + 15) / 16; tile += gsize) {
+        cf v[CA::E];
+        {
+          const int line = t & 15, u = t >> 4;                             // thread_map<CA, 0>: 32 butterflies of 32 points per column
+          const int n2r = (int)(tile * 16u) + line, n2 = n2r > N2 / 2 ? N2 / 2 : n2r;
+          const int up = u * N2 + n2;
+          const int lo = n2 ? (N1 - 1 - u) * N2 + (N2 - n2) : (N1 - u) * N2;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) {
+            const int step = q * (N1 / 32) * N2;
+            if (q < 16) { const cf x = X[up + step]; v[q] = cf{x.x, -x.y}; }
+            else v[q] = X[lo - step];
+          }
+        }
+        stage_compute_write<CA, 0>(v, aa, tile, t, xb, tw_a, nullptr);
+        __syncthreads();
+        stage_read<CA, 1>(v, aa, tile, t, xb);
+        __syncthreads();
+        stage_compute_write<CA, 1, false, true>(v, aa, tile, t, xb, tw_a, nullptr);      // finished columns stay in LDS: [k1][16]
+        __syncthreads();
+        // adjacent results k1 = 2i, 2i + 1 of column n2: four-step roots, packed as a + i b at n2 and conj(a) + i conj(b) at N2 - n2
+        for (int p = t; p < (N1 / 2) * 16; p += RtCfg::THREADS) {
+          const int i = p >> 4, c = p & 15;
+          const int n2r = (int)(tile * 16u) + c;
+          if (n2r > N2 / 2) continue;
+          const cf a = cmul(xb[(2 * i) * 16 + c], root((unsigned)(2 * i) * (unsigned)n2r));
+          const cf b = cmul(xb[(2 * i + 1) * 16 + c], root((unsigned)(2 * i + 1) * (unsigned)n2r));
+          W[(size_t)i * N2 + n2r] = cf{a.x - b.y, a.y + b.x};
+          if (n2r >= 1 && n2r < N2 / 2) W[(size_t)i * N2 + (N2 - n2r)] = cf{a.x + b.y, b.x - a.y};
+        }
+        __syncthreads();
+      }
+    } else
     for (unsigned tile = rank; tile < (COLS + 15) / 16; tile += gsize) {
       const int line = t & 15, i = t >> 4;
       cf v[64], v0[32], v1[32];

@@ -140,6 +140,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     { const LineKernelMeta ma = make_meta(0, 1024, 32, 32, 1, 16, true, true, false, false, 0);   // r2c 1024 x 2048: LDS-resident pass A + register-tile pass B (fft_xcd_rt_r2c_kernel<1024>)
       XcdKernelMeta m{id++, 1024, 2048, {32, 32, 1}, {64, 32, 1}, 16, 16, false, 512, 0, 1, 1};
       m.lds_bytes = std::max(ma.lds_bytes - ma.tw_elems * 8, 16 * 32 * 32 * 8) + ma.tw_elems * 8 + 31 * 64 * 8 + 64; r.push_back(m); }
+    { const LineKernelMeta ma = make_meta(0, 1024, 32, 32, 1, 16, true, true, false, false, 0);   // c2r 1024 x 2048 (fft_xcd_rt_c2r_kernel<1024>)
+      XcdKernelMeta m{id++, 1024, 2048, {32, 32, 1}, {64, 32, 1}, 16, 16, false, 512, 0, 2, 1};
+      m.lds_bytes = std::max(ma.lds_bytes - ma.tw_elems * 8, 16 * 32 * 32 * 8) + ma.tw_elems * 8 + 31 * 64 * 8 + 64; r.push_back(m); }
     return r;
   }();
   return reg;
