@@ -658,10 +658,11 @@ def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-rt {label} {direction}")
 
 
-@pytest.mark.parametrize("cus,xcds,split,slots,hx,label", [(2, 2, 1, 2, 1, "2wg"), (3, 1, 2, 1, 1, "2wg"), (2, 2, 1, 2, 2, "rt32"), (3, 1, 1, 1, 2, "rt32")])
+@pytest.mark.parametrize("cus,xcds,split,slots,hx,label", [(2, 2, 1, 2, 1, "2wg"), (3, 1, 2, 1, 1, "2wg"), (2, 2, 1, 2, 2, "rt32"), (3, 1, 1, 1, 2, "rt32"), (2, 1, 2, 1, 3, "rt16x2")])
 def test_c2c_xcd_two_workgroups_per_cu(oracle, monkeypatch, cus, xcds, split, slots, hx, label):
     """N = 2^20 on register tiles (kern_regtile.hpp): hx=1 the exchange in two 64 KB halves, 72 KB of LDS and 128 VGPRs per workgroup,
-    two workgroups per CU (fft_xcd_hx_kernel); hx=2 tiles of 32 lines, 256-byte segments (fft_xcd_rt1k_kernel)"""
+    two workgroups per CU (fft_xcd_hx_kernel); hx=2 tiles of 32 lines, 256-byte segments (fft_xcd_rt1k_kernel); hx=3 the same code on 16-line tiles
+    with 256 threads, two workgroups per CU"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_XCD_HX", str(hx))
     monkeypatch.setenv("MI355_EMU_CUS", str(cus))

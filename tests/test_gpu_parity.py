@@ -146,7 +146,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
-@pytest.mark.parametrize("hx,label", [(1, "2wg"), (2, "rt32")])
+@pytest.mark.parametrize("hx,label", [(1, "2wg"), (2, "rt32"), (3, "rt16x2")])
 def test_c2c_two_workgroups_per_cu(fft, dev, oracle, monkeypatch, hx, label):
     """N = 2^20 on the opt-in register-tile kernels (kern_regtile.hpp): hx=1 two workgroups per CU (fft_xcd_hx_kernel; measured slower
     than the shipped kernel, profiles/r03_headline_2wg_ab.log), hx=2 tiles of 32 lines (fft_xcd_rt1k_kernel): 19 transforms over the

@@ -733,49 +733,54 @@ __global__ void __launch_bounds__(HxCfg::THREADS, MI355_HX_WAVES) fft_xcd_hx_ker
 #ifndef MI355_RT1K_W_NT
 #define MI355_RT1K_W_NT 0      /* experiment: nontemporal accesses to the intermediate */
 #endif
-struct Rt1kCfg {
-  static constexpr int N = 1024, T = 32, THREADS = 512;
+// T = 32: one 512-thread workgroup per CU.  T = 16 (r03 experiment, MI355FFT_XCD_HX=3): the same code on 16-line tiles with 256 threads — 72 KB of
+// LDS and still 256 VGPRs per thread, so TWO independent workgroups share a CU and their load / compute / store phases interleave (the 512-thread
+// two-per-CU form of fft_xcd_hx_kernel had to live in 128 VGPRs).
+template <int T_ = 32> struct Rt1kCfgT {
+  static constexpr int N = 1024, T = T_, THREADS = 16 * T_;
   static constexpr int HALF_ELEMS = T * 32 * 16;
   static constexpr int TW1_ELEMS = 31 * 32;
   static constexpr int LDS_BYTES = (HALF_ELEMS + TW1_ELEMS) * 8 + 64;
 };
-MI_DEV int rt1k_slot(int line, int pl, int u) { return u * 512 + pl * 32 + ((line + (u >> 1)) & 31); }
+using Rt1kCfg = Rt1kCfgT<32>;
+template <int T = 32> MI_DEV int rt1k_slot(int line, int pl, int u) { return u * (16 * T) + pl * T + ((line + (u >> 1)) & (T - 1)); }
 
 // producers (line, ua), (line, ub) with outputs va[p], vb[p]; consumers (cl, h) in the first half and (cl, h + 16) in the second.
 // `mid()` runs between the halves' reads, when consumer 0's inputs are in w and the second half is on its way through LDS.
-template <class Mid>
+template <int T = 32, class Mid>
 MI_DEV void rt1k_exchange(const cf (&va)[32], const cf (&vb)[32], cf (&w)[32], cf* xb, int line, int ua, int ub, int cl, int h, Mid&& mid) {
-  const int wa = rt1k_slot(line, 0, ua), wb2 = rt1k_slot(line, 0, ub);
+  const int wa = rt1k_slot<T>(line, 0, ua), wb2 = rt1k_slot<T>(line, 0, ub);
 #pragma unroll
-  for (int p = 0; p < 16; ++p) { xb[wa + p * 32] = va[p]; xb[wb2 + p * 32] = vb[p]; }
+  for (int p = 0; p < 16; ++p) { xb[wa + p * T] = va[p]; xb[wb2 + p * T] = vb[p]; }
   __syncthreads();
 #pragma unroll
-  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 512 + h * 32 + ((cl + (uu >> 1)) & 31)];
+  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * (16 * T) + h * T + ((cl + (uu >> 1)) & (T - 1))];
   __syncthreads();
 #pragma unroll
-  for (int p = 0; p < 16; ++p) { xb[wa + p * 32] = va[16 + p]; xb[wb2 + p * 32] = vb[16 + p]; }
+  for (int p = 0; p < 16; ++p) { xb[wa + p * T] = va[16 + p]; xb[wb2 + p * T] = vb[16 + p]; }
   __syncthreads();
   MI_SCHED_FENCE();
   mid();
   MI_SCHED_FENCE();
 #pragma unroll
-  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * 512 + h * 32 + ((cl + (uu >> 1)) & 31)];
+  for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * (16 * T) + h * T + ((cl + (uu >> 1)) & (T - 1))];
 }
 
-template <bool INV>
-__global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const XcdFusedArgs f) {
+template <bool INV, int T = 32>
+__global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(const XcdFusedArgs f) {   // (2 waves per SIMD: 256 registers per thread, VGPRs + AGPRs, for either tile width)
+  using K = Rt1kCfgT<T>;
   MI_SMEM_DECL(smem);
   cf* xb = reinterpret_cast<cf*>(smem);
-  cf* tw1 = xb + Rt1kCfg::HALF_ELEMS;
-  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + Rt1kCfg::TW1_ELEMS);
+  cf* tw1 = xb + K::HALF_ELEMS;
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + K::TW1_ELEMS);
   const int t = threadIdx.x;
-  for (int i = t; i < Rt1kCfg::TW1_ELEMS; i += Rt1kCfg::THREADS) tw1[i] = f.tw_a[i];
+  for (int i = t; i < K::TW1_ELEMS; i += K::THREADS) tw1[i] = f.tw_a[i];
   if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
-  constexpr unsigned N1 = 1024, N2 = 1024, NT = 32;
+  constexpr unsigned N1 = 1024, N2 = 1024, NT = 1024 / T, TU = (unsigned)T;
   const bool two_slots = f.slots != 1u;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
-  const int cl = t & 31, h = t >> 5;        // column-side map
+  const int cl = t & (T - 1), h = t / T;    // column-side map
   const int rl = t >> 4, hh = t & 15;       // row-side map
   const auto root = [&](unsigned m) { return cmul(f.tw_hi[m >> f.fs_shift], f.tw_lo[m & f.fs_lo_mask]); };
   const auto stage1 = [&](cf (&w)[32], int j2) {
@@ -801,12 +806,12 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
       const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
       constexpr int PF = MI355_RT1K_PREFETCH;     // how many of va's 32 loads are requested one tile ahead
       const auto load_a = [&](unsigned tile, int q0, int q1) {
-        const cf* p = x + tile * 32u;
+        const cf* p = x + tile * TU;
 #pragma unroll
         for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) va[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
       };
       const auto load_b = [&](unsigned tile) {
-        const cf* p = x + tile * 32u;
+        const cf* p = x + tile * TU;
 #pragma unroll
         for (int q = 0; q < 32; ++q) vb[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff));
       };
@@ -816,9 +821,9 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
         load_b(tile);
         fft_radix<32>(va);
         fft_radix<32>(vb);
-        cf* const po = W + tile * 32u;
+        cf* const po = W + tile * TU;
         const unsigned so = (unsigned)h * N2 + (unsigned)cl;
-        rt1k_exchange(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
+        rt1k_exchange<T>(va, vb, w, xb, cl, h, h + 16, cl, h, [&] {
           if (PF && tile + gsize < NT) load_a(tile + gsize, 0, PF);
           stage1(w, h);
 #pragma unroll
@@ -839,7 +844,7 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
       const unsigned lo = (unsigned)rl * N2 + 2u * (unsigned)hh;
       constexpr int PF = MI355_RT1K_PREFETCH / 2;  // how many of the 32 16-byte loads are requested one tile ahead
       const auto load_rows = [&](unsigned tile, int q0, int q1) {      // elements 2hh + 32q and 2hh + 1 + 32q of row 32 tile + rl, q = q0 .. q1 - 1
-        const cf* p = W + (size_t)(tile * 32u) * N2;
+        const cf* p = W + (size_t)(tile * TU) * N2;
 #pragma unroll
         for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) {
           const cf4 pr = *reinterpret_cast<const cf4*>(sgpr_base(p + 32 * q) + lo);
@@ -850,7 +855,7 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
       for (unsigned tile = rank; tile < NT; tile += gsize) {
         load_rows(tile, PF, 32);
         {
-          const unsigned k1 = tile * 32u + (unsigned)rl;
+          const unsigned k1 = tile * TU + (unsigned)rl;
           const cf step = root(k1 * 32u), one = root(k1);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -865,7 +870,7 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
         }
         fft_radix<32>(va);
         fft_radix<32>(vb);
-        cf* const po = y + tile * 32u;
+        cf* const po = y + tile * TU;
         const unsigned so = (unsigned)h * N1 + (unsigned)cl;
         const auto store = [&](cf (&ww)[32], unsigned off) {
 #pragma unroll
@@ -875,7 +880,7 @@ __global__ void __launch_bounds__(Rt1kCfg::THREADS) fft_xcd_rt1k_kernel(const Xc
             st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
           }
         };
-        rt1k_exchange(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] {
+        rt1k_exchange<T>(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] {
           if (PF && tile + gsize < NT) load_rows(tile + gsize, 0, PF);
           stage1(w, h); store(w, 0u);
         });

@@ -143,6 +143,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     { const LineKernelMeta ma = make_meta(0, 1024, 32, 32, 1, 16, true, true, false, false, 0);   // c2r 1024 x 2048 (fft_xcd_rt_c2r_kernel<1024>)
       XcdKernelMeta m{id++, 1024, 2048, {32, 32, 1}, {64, 32, 1}, 16, 16, false, 512, 0, 2, 1};
       m.lds_bytes = std::max(ma.lds_bytes - ma.tw_elems * 8, 16 * 32 * 32 * 8) + ma.tw_elems * 8 + 31 * 64 * 8 + 64; r.push_back(m); }
+    for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 on 16-line register tiles, 256 threads, two workgroups per CU (fft_xcd_rt1k_kernel<.., 16>): rt = 5
+      XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 16, 16, inv != 0, 256, (16 * 32 * 16 + 31 * 32) * 8 + 64, 0, 5}; r.push_back(m);
+    }
     return r;
   }();
   return reg;
@@ -674,7 +677,7 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry())
-        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : m.rt == 5 ? opt.xcd_hx == 3 : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
         const bool a_rt = xm->rt == 1 && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
@@ -714,7 +717,7 @@ struct Builder {
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
         if (!solo && opt.xcd_fused != 2 && ((xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) || xm->rt == 2)) grid *= 2;
         st.grid = (unsigned)grid;
-        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt == 3 ? "xcd-fused-rt32[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt == 3 ? "xcd-fused-rt32[N=" : xm->rt == 5 ? "xcd-fused-rt16x2[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }
