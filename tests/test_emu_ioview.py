@@ -173,6 +173,51 @@ def test_c2c_sides_fused_into_the_line_kernels(oracle, monkeypatch, shape, io_vi
             assert staging and "mapped[" not in route, route
 
 
+@pytest.mark.parametrize("clear", [False, True])
+def test_c2c_view_of_a_four_step_line(oracle, monkeypatch, clear):
+    """r03: a rank-1 view of a 2^20-point line — pad-in-read (the input view is shorter and shifted), zeroPad.read / .write ranges, crop +
+    embed-in-write (the output view is a shifted window, optionally cleared outside) — as predicates of the fused kernel's loads and stores
+    (kern_regtile.hpp fft_xcd_rt1k_kernel<.., VIEW>): control-block reset + ONE launch (+ the clearOutside memset), no embed / zero / extract"""
+    monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
+    monkeypatch.setenv("MI355_EMU_CUS", "3")
+    monkeypatch.setenv("MI355_EMU_XCDS", "1")
+    n, batch = 1 << 20, 2
+    vin = {"shape": [n - 3000], "offset": [1000]}            # logical i <- view element i - 1000
+    vout = {"shape": [n // 2 + 77], "offset": [-50], "clearOutside": clear}   # view element j <- logical j - 50
+    zr, zw = {"start": [5000], "end": [n - 100]}, {"start": [64], "end": [n // 2 - 5]}
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(2 * vin["shape"][0] * batch).astype(np.float32)
+    out_init = rng.standard_normal(2 * vout["shape"][0] * batch).astype(np.float32)
+    for direction, norm in (("forward", "none"), ("inverse", "backward")):
+        desc, _ = _desc({"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm,
+                         "ioView": {"input": vin, "output": vout}, "zeroPad": {"read": zr, "write": zw}})
+        got, route, launches = emu.run_plan(desc, x, out_init.size, out_init=out_init)
+        assert "xcd-fused-view[N=1024x1024]" in route and launches == (3 if clear else 2), (route, launches)
+        assert not any(w in route for w in ("embed", "extract", "zero-", "gather", "scatter")), route
+        # numpy restatement (rank 1, vectorised)
+        logical = np.zeros((batch, n, 2), np.float32)
+        v = x.reshape(batch, -1, 2)
+        lo, hi = max(0, vin["offset"][0]), min(n, vin["offset"][0] + vin["shape"][0])
+        logical[:, lo:hi] = v[:, lo - vin["offset"][0]:hi - vin["offset"][0]]
+        logical[:, :zr["start"][0]] = 0
+        logical[:, zr["end"][0]:] = 0
+        y = oracle.c2c_ref_batch(logical.reshape(-1), [n], batch, direction, norm).reshape(batch, n, 2)
+        y[:, :zw["start"][0]] = 0
+        y[:, zw["end"][0]:] = 0
+        want = out_init.reshape(batch, -1, 2).copy()
+        if clear:
+            want[...] = 0
+        j0 = max(0, -vout["offset"][0])
+        j1 = min(vout["shape"][0], n - vout["offset"][0])
+        want[:, j0:j1] = y[:, j0 + vout["offset"][0]:j1 + vout["offset"][0]]
+        from oracle import oracle as orc
+        assert orc.rel_l2(got, want.reshape(-1)) < 1e-5 and orc.rel_max(got, want.reshape(-1)) < 1e-5, route
+        untouched = np.ones(vout["shape"][0], bool)
+        untouched[j0:j1] = False
+        if not clear:
+            assert np.array_equal(got.reshape(batch, -1, 2)[:, untouched], out_init.reshape(batch, -1, 2)[:, untouched])
+
+
 def test_noop_views_resolve_to_nothing():
     _, r = _desc({"type": "c2c", "shape": [8, 4], "direction": "forward", "ioView": {"input": {"shape": [8, 4]}, "output": {"shape": [8, 4], "offset": [0, 0]}},
                   "zeroPad": {"read": {"start": [0, 0], "end": [8, 4]}}})

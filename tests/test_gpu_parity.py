@@ -436,6 +436,38 @@ def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
 
 
 @pytest.mark.parametrize("fuse", [1, 0])
+def test_c2c_view_of_a_four_step_line(fft, dev, oracle, monkeypatch, fuse):
+    """r03: rank-1 ioView + zeroPad of a 2^20-point line as predicates of the fused kernel's loads and stores (fuse=1: control-block reset +
+    one launch, route free of embed / zero / extract) against the staging route (fuse=0) and the numpy restatement of the semantics"""
+    monkeypatch.setenv("MI355FFT_FUSE_VIEWS", str(fuse))
+    n, batch = 1 << 20, 11
+    vin = {"shape": [n - 3000], "offset": [1000]}
+    vout = {"shape": [n // 2 + 77], "offset": [-50], "clearOutside": False}
+    zr, zw = {"start": [5000], "end": [n - 100]}, {"start": [64], "end": [n // 2 - 5]}
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal(2 * vin["shape"][0] * batch).astype(np.float32)
+    out_init = rng.standard_normal(2 * vout["shape"][0] * batch).astype(np.float32)
+    opts = {"type": "c2c", "shape": [n], "batch": batch, "direction": "forward", "normalize": "none",
+            "ioView": {"input": vin, "output": vout}, "zeroPad": {"read": zr, "write": zw}}
+    got, (route, launches) = run_plan(fft, dev, opts, x, out_init.size, out_init=out_init)
+    if fuse:
+        assert "xcd-fused-view[N=1024x1024]" in route and launches == 2 and not any(w in route for w in ("embed", "extract", "zero-")), route
+    else:
+        assert "embed" in route and "extract" in route, route
+    logical = np.zeros((batch, n, 2), np.float32)
+    logical[:, 1000:n - 2000] = x.reshape(batch, -1, 2)
+    logical[:, :zr["start"][0]] = 0
+    logical[:, zr["end"][0]:] = 0
+    y = oracle.c2c_ref_batch(logical.reshape(-1), [n], batch, "forward", "none").reshape(batch, n, 2)
+    y[:, :zw["start"][0]] = 0
+    y[:, zw["end"][0]:] = 0
+    want = out_init.reshape(batch, -1, 2).copy()
+    want[:, 50:] = y[:, :vout["shape"][0] - 50]
+    check(oracle, got, want.reshape(-1), route, 2e-3, 2e-3)
+    assert np.array_equal(got.reshape(batch, -1, 2)[:, :50], out_init.reshape(batch, -1, 2)[:, :50])
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
 def test_c2c_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
     """pad-in-read + embed-in-write (clearOutside) + range zeroing, checked against the emu-tier numpy restatement.  fuse=1: both
     sides ride the first load / last store of the line kernels (no separate passes); fuse=0: the staging route"""

@@ -143,7 +143,7 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
 #define MI_XCD_PLUS2(...) +2
 #define MI_XCD_PLUS1(...) +1
 constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1)
-                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_RT_KERNEL_LIST(MI_XCD_PLUS2) + 1 + 2 + 1 + 2 + 1 + 1 + 1 + 2;   // (+ 1024 x 1024 on 16-line register tiles, two 256-thread workgroups per CU: forward, inverse) (+ the register-tile r2c and c2r 1024 x 2048) (+ the fftconv pipeline for 2^20 points) + the register-tile r2c 2048 x 2048 + the two-workgroups-per-CU 1024 x 1024 (forward, inverse) + the register-tile c2r 2048 x 2048 + the 32-line register-tile 1024 x 1024 (forward, inverse)
+                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_RT_KERNEL_LIST(MI_XCD_PLUS2) + 1 + 2 + 1 + 2 + 1 + 1 + 1 + 2 + 2;   // (+ the VIEW instances of the 32-line 1024 x 1024 kernel) (+ 1024 x 1024 on 16-line register tiles, two 256-thread workgroups per CU: forward, inverse) (+ the register-tile r2c and c2r 1024 x 2048) (+ the fftconv pipeline for 2^20 points) + the register-tile r2c 2048 x 2048 + the two-workgroups-per-CU 1024 x 1024 (forward, inverse) + the register-tile c2r 2048 x 2048 + the 32-line register-tile 1024 x 1024 (forward, inverse)
 #undef MI_XCD_PLUS2
 #undef MI_XCD_PLUS1
 
@@ -266,6 +266,18 @@ template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, 
       if (id == ME) { l.launch_concurrent(fft_xcd_rt1k_kernel<true, 16>, grid, (unsigned)Rt1kCfgT<16>::THREADS, (unsigned)Rt1kCfgT<16>::LDS_BYTES, a); return true; }
     }
   }
+  {
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;
+    if constexpr (ONLY < 0 || ONLY == ME) {
+      if (id == ME) { l.launch_concurrent(fft_xcd_rt1k_kernel<false, 32, true>, grid, (unsigned)Rt1kCfg::THREADS, (unsigned)Rt1kCfg::LDS_BYTES, a); return true; }
+    }
+  }
+  {
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;
+    if constexpr (ONLY < 0 || ONLY == ME) {
+      if (id == ME) { l.launch_concurrent(fft_xcd_rt1k_kernel<true, 32, true>, grid, (unsigned)Rt1kCfg::THREADS, (unsigned)Rt1kCfg::LDS_BYTES, a); return true; }
+    }
+  }
   static_assert(__COUNTER__ - MI_XCD_COUNTER_BASE == XCD_INSTANCE_COUNT, "instance ids out of step with the lists");
   return false;
 }
@@ -370,6 +382,8 @@ bool dispatch_step(const Step& s, void* const ptr[5], L& l, LinesFn&& lines_fn, 
       a.split = (unsigned)s.i[8]; a.slots = (unsigned)s.i[11]; a.solo = (unsigned)s.i[12];
       a.conv_k = (unsigned)s.i[15]; a.conv_conj = (unsigned)s.i[16]; a.out_kernel_pitch = s.i[17];
       a.mul = a.conv_k ? (const cf*)((const char*)ptr[2] + s.i[14]) : nullptr;   // the kernel spectra sit in the same workspace arena as the slots
+      a.v_in_lo = (int)s.imap.lo[0]; a.v_in_hi = (int)s.imap.hi[0]; a.v_out_lo = (int)s.omap.lo[0]; a.v_out_hi = (int)s.omap.hi[0];
+      a.v_zlo = (int)s.omap.zlo[0]; a.v_zhi = (int)s.omap.zhi[0];   // (VIEW instances only; the planner fills the two maps)
       if (s.kind == ST_XCD_RES) return launch_xcd_res(s.variant, a, s.grid, l);
       return xcd_fn(s.variant, a, s.grid);
     }

@@ -766,7 +766,9 @@ MI_DEV void rt1k_exchange(const cf (&va)[32], const cf (&vb)[32], cf (&w)[32], c
   for (int uu = 0; uu < 32; ++uu) w[uu] = xb[uu * (16 * T) + h * T + ((cl + (uu >> 1)) & (T - 1))];
 }
 
-template <bool INV, int T = 32>
+// VIEW (r03; src/kernels/ioview.js:56-380, zero_pad.js:21-80 for a 2^20-point line): pad-in-read / crop / zero ranges are predicates of pass A's
+// loads and pass B's stores (XcdFusedArgs::v_*), so a view of a four-step line needs no embed / zero / extract launch either.
+template <bool INV, int T = 32, bool VIEW = false>
 __global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(const XcdFusedArgs f) {   // (2 waves per SIMD: 256 registers per thread, VGPRs + AGPRs, for either tile width)
   using K = Rt1kCfgT<T>;
   MI_SMEM_DECL(smem);
@@ -805,15 +807,24 @@ __global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(c
       cf va[32], vb[32], w[32];
       const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
       constexpr int PF = MI355_RT1K_PREFETCH;     // how many of va's 32 loads are requested one tile ahead
+      const auto load_x = [&](const cf* p, unsigned row_uniform, unsigned tile) {     // element (row_uniform + h) * N2 + tile * T + cl of the line
+        if constexpr (VIEW) {
+          const int i = (int)((row_uniform + (unsigned)h) * N2 + tile * TU + (unsigned)cl);
+          const cf* const pe = p + row_uniform * N2 + voff;
+          cf xv = {0.0f, 0.0f};
+          if (i >= f.v_in_lo && i < f.v_in_hi) xv = *pe;
+          return cswap_if<INV>(xv);
+        } else return cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + row_uniform * N2) + voff));
+      };
       const auto load_a = [&](unsigned tile, int q0, int q1) {
         const cf* p = x + tile * TU;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) va[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q) * N2) + voff));
+        for (int q = 0; q < 32; ++q) if (q >= q0 && q < q1) va[q] = load_x(p, (unsigned)(32 * q), tile);
       };
       const auto load_b = [&](unsigned tile) {
         const cf* p = x + tile * TU;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) vb[q] = cswap_if<INV>(ld_stream<MI355_RT1K_NT_IN != 0>(sgpr_base(p + (unsigned)(32 * q + 16) * N2) + voff));
+        for (int q = 0; q < 32; ++q) vb[q] = load_x(p, (unsigned)(32 * q + 16), tile);
       };
       if (PF && rank < NT) load_a(rank, 0, PF);
       for (unsigned tile = rank; tile < NT; tile += gsize) {
@@ -877,7 +888,12 @@ __global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(c
           for (int q = 0; q < 32; ++q) {
             cf r = ww[q];
             if (f.scale != 1.0f) r = r * f.scale;
-            st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
+            if constexpr (VIEW) {
+              const int kk = (int)(((unsigned)(32 * q) + off + (unsigned)h) * N1 + tile * TU + (unsigned)cl);      // k = k1 + N1 k2
+              cf* const pe = po + ((unsigned)(32 * q) + off) * N1 + so;
+              if (kk < f.v_zlo || kk >= f.v_zhi) r = cf{0.0f, 0.0f};
+              if (kk >= f.v_out_lo && kk < f.v_out_hi) *pe = cswap_if<INV>(r);
+            } else st_stream<MI355_RT1K_NT_OUT != 0>(sgpr_base(po + ((unsigned)(32 * q) + off) * N1) + so, cswap_if<INV>(r));
           }
         };
         rt1k_exchange<T>(va, vb, w, xb, rl, 2 * hh, 2 * hh + 1, cl, h, [&] {

@@ -78,6 +78,10 @@ struct XcdFusedArgs {
   const cf* mul;
   unsigned conv_k, conv_conj;    // kernels per data line; 1: correlation (conjugated spectra)
   long long out_kernel_pitch;    // complex elements between the outputs of consecutive kernels of one data line (out_pitch: between data lines)
+  // rank-1 views of the VIEW instances (ioView / zeroPad of a four-step line as predicates of the first loads and the last stores, SideMap
+  // semantics of plan.hpp): element i of a line is read inside [v_in_lo, v_in_hi) and is 0 elsewhere; element k is stored inside
+  // [v_out_lo, v_out_hi) only, as 0 outside [v_zlo, v_zhi).  `in` / `out` already carry the maps' offsets.
+  int v_in_lo, v_in_hi, v_out_lo, v_out_hi, v_zlo, v_zhi;
 };
 
 // roots for one PASS_B tile, generated per tile: anchors by exact table lookup every 8th element, the 7 in between by

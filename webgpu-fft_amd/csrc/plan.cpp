@@ -146,6 +146,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     for (int inv = 0; inv < 2; ++inv) {   // 1024 x 1024 on 16-line register tiles, 256 threads, two workgroups per CU (fft_xcd_rt1k_kernel<.., 16>): rt = 5
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 16, 16, inv != 0, 256, (16 * 32 * 16 + 31 * 32) * 8 + 64, 0, 5}; r.push_back(m);
     }
+    for (int inv = 0; inv < 2; ++inv) {   // VIEW instances of the 32-line 1024 x 1024 kernel (rank-1 ioView / zeroPad as load / store predicates): rt = 6
+      XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 0, 6}; r.push_back(m);
+    }
     return r;
   }();
   return reg;
@@ -517,6 +520,33 @@ struct Builder {
 
   // Lane layouts (channel-lane presets, whdcn with unit stride along the line): contiguous power-of-two lines that sit at
   // arbitrary pitches on either side need no gather / scatter pass — the ROW line kernels take the two pitches as they are.
+  // rank-1 view of a four-step line (ioView / zeroPad / unit-stride lanes) on a VIEW instance of the fused kernels: the maps' ranges are
+  // predicates of pass A's loads and pass B's stores — no embed / zero / extract launch.  false: no instance for this length.
+  bool emit_xcd_view(PtrRef in, PtrRef out, int64_t N, int64_t lines, bool inverse, float scale, const SideMap& im, const SideMap& om) {
+    if (opt.force_generic || opt.xcd_fused != 1 || !opt.xcd_shared || !opt.fuse_views || opt.only_pass) return false;
+    const XcdKernelMeta* xm = nullptr;
+    for (const auto& m : xcd_kernel_registry()) if (m.rt == 6 && (int64_t)m.N1 * m.N2 == N && m.inverse == inverse) xm = &m;
+    if (!xm) return false;
+    int64_t split = 1, slots = 1;
+    xcd_groups((uint64_t)N * 8, false, split, slots);
+    const PtrRef wslots = alloc_work((uint64_t)(16 * slots * split) * N * 8), ctl = alloc_work(40960);
+    std::vector<float2h> lo(1024), hi((size_t)(N >> 10));
+    for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
+    for (int64_t h = 0; h < (N >> 10); ++h) hi[(size_t)h] = root_of_unity(h << 10, N);
+    const LineKernelMeta ml = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
+    const PtrRef ta = line_tables(ml), tlo = add_table(lo), thi = add_table(hi);
+    { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
+    Step& st = push(ST_XCD_FUSED);
+    st.variant = xm->id;
+    st.p[0] = in.plus(im.offset * 8); st.p[1] = out.plus(om.offset * 8); st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
+    st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023; st.i[9] = im.batch_stride; st.i[10] = om.batch_stride;
+    st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = 0; st.i[13] = opt.xcd_spin_limit;
+    st.f[0] = scale;
+    st.imap = im; st.omap = om;
+    st.grid = (unsigned)opt.compute_units;
+    ir.route += "xcd-fused-view[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+    return true;
+  }
   bool emit_lines_pitched(PtrRef src, PtrRef dst, int64_t N, int64_t lines, bool inverse, float scale, int64_t in_pitch, int64_t out_pitch) {
     if (opt.force_generic || !is_pow2(N) || N < 2 || N > opt.max_line || (opt.xcd_fused == 2 && N == 4096)) return false;
     const LineKernelMeta* m = find_line_kernel((int)N, false, false, inverse, inverse, 0);
@@ -677,7 +707,7 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry())
-        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : m.rt == 5 ? opt.xcd_hx == 3 : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : m.rt == 5 ? opt.xcd_hx == 3 : m.rt == 6 ? false : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
         const bool a_rt = xm->rt == 1 && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
@@ -1296,6 +1326,17 @@ int build_c2c(const mi355fft_plan_desc& d, Builder& b, std::string& err) {
       b.lane_in_pitch = b.lane_out_pitch = 0;
       if (rcl == MI355FFT_OK && b.lane_used) { b.ir.route += "lanes[pitch=" + std::to_string(ip) + "/" + std::to_string(op) + "] "; return MI355FFT_OK; }
       b.ir.steps.resize(mark); b.ir.route = route_mark; b.work_top = work_mark; b.ir.work_bytes = work_bytes_mark; err.clear();
+    }
+  }
+
+  // ---- rank-1 views of a four-step line with a VIEW instance (r03): ranges as predicates of the fused kernel's loads and stores ----
+  if (rank == 1 && !d.in_place && (d.axes_mask == 0 || d.axes_mask == 1) && n > b.opt.max_line && (vin || vout || d.zero_read.enabled || d.zero_write.enabled)) {
+    const SideMap im = input_side_map(d, d.shape, 1), om = output_side_map(d, d.shape, 1);
+    if (im.stride[0] == 1 && om.stride[0] == 1 && n < ((int64_t)1 << 30)) {
+      const size_t mark = b.ir.steps.size();
+      if (vout && d.io_output.clear_outside) { Step& z = b.push(ST_ZERO); z.p[0] = out; z.i[0] = out_n * d.batch * 2; z.grid = b.generic_grid(z.i[0]); }
+      if (b.emit_xcd_view(in, out, n, d.batch, inverse, scale, im, om)) return MI355FFT_OK;
+      b.ir.steps.resize(mark);
     }
   }
 
