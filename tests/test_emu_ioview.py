@@ -173,15 +173,15 @@ def test_c2c_sides_fused_into_the_line_kernels(oracle, monkeypatch, shape, io_vi
             assert staging and "mapped[" not in route, route
 
 
-@pytest.mark.parametrize("clear", [False, True])
-def test_c2c_view_of_a_four_step_line(oracle, monkeypatch, clear):
+@pytest.mark.parametrize("lg,label,clear", [(20, "1024x1024", False), (20, "1024x1024", True), (17, "256x512", False), (18, "512x512", True), (19, "512x1024", False)])
+def test_c2c_view_of_a_four_step_line(oracle, monkeypatch, lg, label, clear):
     """r03: a rank-1 view of a 2^20-point line — pad-in-read (the input view is shorter and shifted), zeroPad.read / .write ranges, crop +
     embed-in-write (the output view is a shifted window, optionally cleared outside) — as predicates of the fused kernel's loads and stores
-    (kern_regtile.hpp fft_xcd_rt1k_kernel<.., VIEW>): control-block reset + ONE launch (+ the clearOutside memset), no embed / zero / extract"""
+    (kern_regtile.hpp fft_xcd_rt1k_kernel<.., VIEW> at 2^20, kern_xcd.hpp fft_xcd_fused_kernel<.., VIEW> at 2^17 .. 2^19): control-block reset + ONE launch (+ the clearOutside memset), no embed / zero / extract"""
     monkeypatch.setenv("MI355_EMU_XCD_FUSED", "1")
     monkeypatch.setenv("MI355_EMU_CUS", "3")
     monkeypatch.setenv("MI355_EMU_XCDS", "1")
-    n, batch = 1 << 20, 2
+    n, batch = 1 << lg, 2
     vin = {"shape": [n - 3000], "offset": [1000]}            # logical i <- view element i - 1000
     vout = {"shape": [n // 2 + 77], "offset": [-50], "clearOutside": clear}   # view element j <- logical j - 50
     zr, zw = {"start": [5000], "end": [n - 100]}, {"start": [64], "end": [n // 2 - 5]}
@@ -192,7 +192,7 @@ def test_c2c_view_of_a_four_step_line(oracle, monkeypatch, clear):
         desc, _ = _desc({"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": norm,
                          "ioView": {"input": vin, "output": vout}, "zeroPad": {"read": zr, "write": zw}})
         got, route, launches = emu.run_plan(desc, x, out_init.size, out_init=out_init)
-        assert "xcd-fused-view[N=1024x1024]" in route and launches == (3 if clear else 2), (route, launches)
+        assert f"xcd-fused-view[N={label}]" in route and launches == (3 if clear else 2), (route, launches)
         assert not any(w in route for w in ("embed", "extract", "zero-", "gather", "scatter")), route
         # numpy restatement (rank 1, vectorised)
         logical = np.zeros((batch, n, 2), np.float32)

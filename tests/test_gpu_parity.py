@@ -435,12 +435,12 @@ def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
     assert np.count_nonzero(got == 77.0) == (5000 - n) * batch
 
 
-@pytest.mark.parametrize("fuse", [1, 0])
-def test_c2c_view_of_a_four_step_line(fft, dev, oracle, monkeypatch, fuse):
+@pytest.mark.parametrize("lg,fuse", [(20, 1), (20, 0), (17, 1), (18, 1), (19, 1)])
+def test_c2c_view_of_a_four_step_line(fft, dev, oracle, monkeypatch, lg, fuse):
     """r03: rank-1 ioView + zeroPad of a 2^20-point line as predicates of the fused kernel's loads and stores (fuse=1: control-block reset +
     one launch, route free of embed / zero / extract) against the staging route (fuse=0) and the numpy restatement of the semantics"""
     monkeypatch.setenv("MI355FFT_FUSE_VIEWS", str(fuse))
-    n, batch = 1 << 20, 11
+    n, batch = 1 << lg, 11
     vin = {"shape": [n - 3000], "offset": [1000]}
     vout = {"shape": [n // 2 + 77], "offset": [-50], "clearOutside": False}
     zr, zw = {"start": [5000], "end": [n - 100]}, {"start": [64], "end": [n // 2 - 5]}
@@ -451,7 +451,7 @@ def test_c2c_view_of_a_four_step_line(fft, dev, oracle, monkeypatch, fuse):
             "ioView": {"input": vin, "output": vout}, "zeroPad": {"read": zr, "write": zw}}
     got, (route, launches) = run_plan(fft, dev, opts, x, out_init.size, out_init=out_init)
     if fuse:
-        assert "xcd-fused-view[N=1024x1024]" in route and launches == 2 and not any(w in route for w in ("embed", "extract", "zero-")), route
+        assert "xcd-fused-view[N=" in route and launches == 2 and not any(w in route for w in ("embed", "extract", "zero-")), route
     else:
         assert "embed" in route and "extract" in route, route
     logical = np.zeros((batch, n, 2), np.float32)

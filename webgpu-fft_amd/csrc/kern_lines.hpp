@@ -79,6 +79,7 @@ struct LineArgs {
   unsigned fs_lo_mask;
   int real_mode;         // 4: fft_lines_mul_kernel (tw_lo = kernel spectrum, fs_shift != 0: conjugate it);  1: fft_lines_r2c_kernel (real line read as complex pairs, split fused behind the last stage); 2: fft_lines_c2r_kernel
   long long fs_group;    // TWID_FOURSTEP_IN: lines per group (line index inside the group = G % fs_group); COL_RAGGED: tiles per group
+  int v_in_lo, v_in_hi, v_out_lo, v_out_hi, v_zlo, v_zhi;   // VIEW instantiations of stage_read / stage_compute_write (kern_xcd.hpp fused kernels): rank-1 ranges of a four-step line
   int mapped;            // fft_lines_mapped_kernel: both sides go through imap / omap (in / out are the buffers' bases)
   SideMap imap, omap;
 };
@@ -192,7 +193,9 @@ MI_DEV void fourstep_in_roots(cf (&fsw)[C::E], const LineArgs& a, long long tile
   }
 }
 
-template <class C, int S, bool NT = false>
+// VIEW (column-mapped first stage of a fused four-step kernel): element idx * in_S + (column of the line) of the transform is read inside
+// [v_in_lo, v_in_hi) and is 0 elsewhere (rank-1 ioView.input / zeroPad.read)
+template <class C, int S, bool NT = false, bool VIEW = false>
 MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, const cf* lds) {
   using I = StageInfo<C, S>;
   int line, u; thread_map<C, S>(t, line, u);
@@ -218,6 +221,13 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
 #pragma unroll
       for (int q = 0; q < I::R; ++q) {
         const cf* pq = p + (unsigned)(b * C::TPL + q * (C::N / I::R)) * es;   // uniform
+        if constexpr (VIEW) {
+          static_assert(C::IN_COL, "views ride the column-mapped pass A");
+          const int i = (int)((unsigned)(u + b * C::TPL + q * (C::N / I::R)) * es + (unsigned)(G0 % a.in_S) + (unsigned)line);
+          cf xv = {0.0f, 0.0f};
+          if (i >= a.v_in_lo && i < a.v_in_hi) xv = pq[voff];
+          v[b * I::R + q] = cswap_if<C::SWAP_IN>(xv);
+        } else
         v[b * I::R + q] = cswap_if<C::SWAP_IN>(ld_stream<NT>(pq + voff));
       }
     }
@@ -235,7 +245,7 @@ MI_DEV void stage_read(cf (&v)[C::E], const LineArgs& a, long long tile, int t, 
 // global memory — for kernels that post-process a whole line before it leaves the workgroup (kern_xcd_real.hpp)
 // MUL: the finished outputs are multiplied by the spectrum a.tw_lo[k] (conjugated when a.fs_shift != 0) on their way out — the
 // pointwise product of fftconv folded into the last stage's register store (fft_lines_mul_kernel)
-template <class C, int S, bool NT = false, bool KEEP_IN_LDS = false, bool MUL = false>
+template <class C, int S, bool NT = false, bool KEEP_IN_LDS = false, bool MUL = false, bool VIEW = false>
 MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile, int t, cf* lds, const cf* tw_lds, const cf* lo_lds) {
   using I = StageInfo<C, S>;
   constexpr bool TO_GLOBAL = I::LAST && !KEEP_IN_LDS;
@@ -290,6 +300,12 @@ MI_DEV void stage_compute_write(cf (&v)[C::E], const LineArgs& a, long long tile
         // last stage: Ns_prev = N/R, so oidx = j + q*(N/R): the q term is uniform
         cf* pq = po + (unsigned)(b * C::TPL + q * I::NSP) * es;
         const unsigned voff = (unsigned)line * ls + (unsigned)u * es;
+        if constexpr (VIEW) {   // transposed store of pass B: element k = oidx * out_S + (row of the line): inside [v_out_lo, v_out_hi) only, 0 outside [v_zlo, v_zhi)
+          static_assert(C::OUT_COL, "views ride the transposed store of pass B");
+          const int kk = (int)((unsigned)oidx * es + (unsigned)((tile * C::T) % a.out_S) + (unsigned)line);
+          if (kk < a.v_zlo || kk >= a.v_zhi) r = cf{0.0f, 0.0f};
+          if (live && kk >= a.v_out_lo && kk < a.v_out_hi) pq[voff] = cswap_if<C::SWAP_OUT>(r);
+        } else
         if (live) st_stream<NT>(pq + voff, cswap_if<C::SWAP_OUT>(r));
       } else {
         lds[lds_index<C>(line, oidx)] = w[q];

@@ -225,7 +225,7 @@ template <class CA, class CB> struct XcdTables {
   static constexpr int ELEMS = CA::TW_ELEMS + (SHARED ? 0 : CB::TW_ELEMS);
 };
 
-template <class CA, class CB>
+template <class CA, class CB, bool VIEW = false>
 __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFusedArgs f) {
   static_assert(CA::THREADS == CB::THREADS, "both passes run in the same workgroup");
   static_assert(CA::IN_COL && CA::OUT_COL && !CB::IN_COL, "PASS_A, then PASS_B (four-step) or ROW (two-dimensional)");
@@ -255,6 +255,10 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
   aa.in_S = N2; aa.in_outer_stride = f.N; aa.out_S = N2; aa.out_outer_stride = f.N; aa.scale = 1.0f; aa.fs_group = 1;
   ab.tw = f.tw_b; ab.num_tiles = N1 / CB::T; ab.num_lines = N1;
   ab.in_S = 1; ab.in_outer_stride = N2; ab.out_S = TWO_D ? 1 : N1; ab.out_outer_stride = TWO_D ? N2 : f.N; ab.scale = f.scale; ab.fs_group = N1;
+  if constexpr (VIEW) {
+    static_assert(!TWO_D && CB::NSTAGES >= 2 && CB::NSTAGES <= 3, "rank-1 views of four-step lines");
+    aa.v_in_lo = f.v_in_lo; aa.v_in_hi = f.v_in_hi; ab.v_out_lo = f.v_out_lo; ab.v_out_hi = f.v_out_hi; ab.v_zlo = f.v_zlo; ab.v_zhi = f.v_zhi;
+  }
   // Two workspace slots per group, alternated per transform: the barrier between A(k+1) and B(k+1) also orders "everyone
   // finished reading slot s in B(k)" before "anyone overwrites slot s in A(k+2)" — one group barrier per transform.
   // (Measured: running A(k+1) ahead of the wait for barrier k, to hide the barrier, loses more than it gains: 150 vs 165
@@ -271,7 +275,7 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
       if (tile - (i % PairOf<CA>::C) >= aa.num_tiles) break;
       if (tile >= aa.num_tiles) continue;
       cf v[CA::E];
-      stage_read<CA, 0, PairOf<CA>::NT>(v, aa, tile, t, lds);       // x streams past the L2
+      stage_read<CA, 0, PairOf<CA>::NT && !VIEW, VIEW>(v, aa, tile, t, lds);       // x streams past the L2
       stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
       if constexpr (CA::NSTAGES >= 2) {
         __syncthreads();
@@ -309,13 +313,13 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_fused_kernel(const XcdFus
         __syncthreads();
         stage_read<CB, 1>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 1, PairOf<CB>::NT>(v, ab, tile, t, lds, tw_b, nullptr);   // output streams past the L2
+        stage_compute_write<CB, 1, PairOf<CB>::NT, false, false, VIEW && CB::NSTAGES == 2>(v, ab, tile, t, lds, tw_b, nullptr);   // output streams past the L2
       }
       if constexpr (CB::NSTAGES == 3) {
         __syncthreads();
         stage_read<CB, 2>(v, ab, tile, t, lds);
         __syncthreads();
-        stage_compute_write<CB, 2, PairOf<CB>::NT>(v, ab, tile, t, lds, tw_b, nullptr);
+        stage_compute_write<CB, 2, PairOf<CB>::NT, false, false, VIEW>(v, ab, tile, t, lds, tw_b, nullptr);
       }
       __syncthreads();
     }

@@ -149,6 +149,18 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
     for (int inv = 0; inv < 2; ++inv) {   // VIEW instances of the 32-line 1024 x 1024 kernel (rank-1 ioView / zeroPad as load / store predicates): rt = 6
       XcdKernelMeta m{id++, 1024, 1024, {32, 32, 1}, {32, 32, 1}, 32, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32) * 8 + 64, 0, 6}; r.push_back(m);
     }
+#define X(N1, A0, A1, A2, TA, N2, B0, B1, B2, TB)                                                          \
+  for (int inv = 0; inv < 2; ++inv) {   /* VIEW instances of the LDS-resident fused kernel: rt = 6 */     \
+    const LineKernelMeta ma = make_meta(0, N1, A0, A1, A2, TA, true, true, inv != 0, false, 0);           \
+    const LineKernelMeta mb = make_meta(0, N2, B0, B1, B2, TB, false, true, false, inv != 0, 0);          \
+    XcdKernelMeta m{id++, N1, N2, {A0, A1, A2}, {B0, B1, B2}, TA, TB, inv != 0, ma.threads, 0, 0, 6};     \
+    const int da = ma.lds_bytes - ma.tw_elems * 8, db = mb.lds_bytes - mb.tw_elems * 8;                   \
+    const bool shared = N1 == N2 && A0 == B0 && A1 == B1 && A2 == B2;                                     \
+    m.lds_bytes = (da > db ? da : db) + (ma.tw_elems + (shared ? 0 : mb.tw_elems)) * 8 + 64;              \
+    r.push_back(m);                                                                                       \
+  }
+    MI355_XCD_VIEW_KERNEL_LIST(X)
+#undef X
     return r;
   }();
   return reg;
@@ -530,20 +542,22 @@ struct Builder {
     int64_t split = 1, slots = 1;
     xcd_groups((uint64_t)N * 8, false, split, slots);
     const PtrRef wslots = alloc_work((uint64_t)(16 * slots * split) * N * 8), ctl = alloc_work(40960);
-    std::vector<float2h> lo(1024), hi((size_t)(N >> 10));
-    for (int64_t l = 0; l < 1024; ++l) lo[(size_t)l] = root_of_unity(l, N);
-    for (int64_t h = 0; h < (N >> 10); ++h) hi[(size_t)h] = root_of_unity(h << 10, N);
+    const int shift = N >= (1 << 20) ? 10 : lg2(N) / 2;                // LO table of 2^shift roots, HI of N >> shift (as emit_axis)
+    std::vector<float2h> lo((size_t)1 << shift), hi((size_t)(N >> shift));
+    for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
+    for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
     const LineKernelMeta ml = make_meta(0, xm->N1, xm->ra[0], xm->ra[1], xm->ra[2], xm->ta, true, true, false, false, 0);
-    const PtrRef ta = line_tables(ml), tlo = add_table(lo), thi = add_table(hi);
+    const LineKernelMeta mr = make_meta(0, xm->N2, xm->rb[0], xm->rb[1], xm->rb[2], xm->tb, false, true, false, false, 0);
+    const PtrRef ta = line_tables(ml), tb = line_tables(mr), tlo = add_table(lo), thi = add_table(hi);
     { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
     Step& st = push(ST_XCD_FUSED);
     st.variant = xm->id;
     st.p[0] = in.plus(im.offset * 8); st.p[1] = out.plus(om.offset * 8); st.p[2] = wslots; st.p[3] = ctl; st.p[4] = PtrRef(BUF_TABLE, 0);
-    st.i[0] = lines; st.i[1] = N; st.i[2] = 10; st.i[3] = 1023; st.i[9] = im.batch_stride; st.i[10] = om.batch_stride;
-    st.i[4] = ta.off; st.i[5] = ta.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = 0; st.i[13] = opt.xcd_spin_limit;
+    st.i[0] = lines; st.i[1] = N; st.i[2] = shift; st.i[3] = ((int64_t)1 << shift) - 1; st.i[9] = im.batch_stride; st.i[10] = om.batch_stride;
+    st.i[4] = ta.off; st.i[5] = tb.off; st.i[6] = tlo.off; st.i[7] = thi.off; st.i[8] = split; st.i[11] = slots; st.i[12] = 0; st.i[13] = opt.xcd_spin_limit;
     st.f[0] = scale;
     st.imap = im; st.omap = om;
-    st.grid = (unsigned)opt.compute_units;
+    st.grid = (unsigned)(opt.compute_units * ((xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) ? 2 : 1));
     ir.route += "xcd-fused-view[N=" + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
     return true;
   }
