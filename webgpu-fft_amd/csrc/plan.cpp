@@ -421,7 +421,10 @@ struct Builder {
       wslots = alloc_work((uint64_t)grid * wsize * 8);
       ctl = alloc_work(256);
     } else {
-      xcd_groups((uint64_t)wsize * 8, xm->rt == 1 && xm->N1 == 2048, split, slots);
+      xcd_groups((uint64_t)wsize * 8, false, split, slots);
+      // 2048 x 2048 real transforms: two groups per XCD with one slot each (8 x 2 x 16.8 MB, a little over the Infinity Cache) measured
+      // ahead of one group with two slots on three of four boxes (r2c 288 vs 279, 282 vs 270, 269 vs 264, 232 vs 238: profiles/r03_regtile_ab.log)
+      if (xm->rt == 1 && xm->N1 == 2048 && opt.xcd_split <= 0 && opt.xcd_slots <= 0) { split = 2; slots = 1; }
       wslots = alloc_work((uint64_t)(16 * slots * split) * wsize * 8);
       ctl = alloc_work(40960);
     }
