@@ -639,7 +639,7 @@ def test_c2c_xcd_fused_route(oracle, monkeypatch, cus, xcds, split, slots):
     check(got, oracle.c2c_ref_batch(x, [n], batch, "forward", "unitary"), "xcd-fused in place")
 
 
-@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(21, "1024x2048", 3, 1, 1, 1), (22, "2048x2048", 4, 2, 2, 2)])
+@pytest.mark.parametrize("lg,label,cus,xcds,split,slots", [(21, "1024x2048", 3, 1, 1, 1), (22, "2048x2048", 4, 2, 2, 2), (21, "2048x1024", 3, 1, 0, 0)])
 def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots):
     """2048-point sides on register-resident 16-line tiles (kern_regtile.hpp): 64-point DFT in registers, one exchange through LDS in
     two halves, radix-32 stage; 2^21 = LDS-resident pass A + register-tile pass B, 2^22 = register tiles on both passes.
@@ -649,12 +649,14 @@ def test_c2c_xcd_regtile(oracle, monkeypatch, lg, label, cus, xcds, split, slots
     monkeypatch.setenv("MI355_EMU_XCDS", str(xcds))
     monkeypatch.setenv("MI355_EMU_XCD_SPLIT", str(split))
     monkeypatch.setenv("MI355_EMU_XCD_SLOTS", str(slots))
+    if lg == 21:                                          # c2c 2^21 ships on the LDS-resident instance; its two register-tile forms are opt-in
+        monkeypatch.setenv("MI355_EMU_XCD_RT", "2" if label == "1024x2048" else "3")
     n, batch = 1 << lg, 3
     x = oracle.random_complex_batch(n, batch, 0x2700 + lg).reshape(-1)
     for direction, norm in (("forward", "none"), ("inverse", "backward")):
         desc = _abi.make_desc("c2c", [n], batch, direction, norm)
         got, route, launches = emu.run_plan(desc, x, x.size)
-        assert route.startswith(f"xcd-fused-rt[N={label}]") and launches == 2, route
+        assert route.startswith(f"xcd-fused-rt32[N={label}]" if label == "2048x1024" else f"xcd-fused-rt[N={label}]") and launches == 2, route
         check(got, oracle.c2c_ref_batch(x, [n], batch, direction, norm), f"xcd-fused-rt {label} {direction}")
 
 

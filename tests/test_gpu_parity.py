@@ -126,14 +126,15 @@ def test_c2c_in_place_and_offsets(fft, dev, oracle):
 FUSED_LG = (15, 16, 17, 18, 19, 20, 21, 22)   # 15-17: solo mode; 21, 22 (r03): register-tile instances   # MI355_XCD_KERNEL_LIST / MI355_XCD_RT_KERNEL_LIST (plan.hpp)
 
 
-@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("fused", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("lg", [13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
 def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     """four-step sizes on both routes: the two-launch route and (where an instance exists) the XCD-fused launch"""
-    if fused and lg not in FUSED_LG or (fused == 2 and lg not in (20, 21)):
+    if fused and lg not in FUSED_LG or (fused == 2 and lg != 20) or (fused >= 3 and lg != 21):
         pytest.skip("no fused instance")
     monkeypatch.setenv("MI355FFT_XCD_FUSED", str(min(fused, 1)))
-    monkeypatch.setenv("MI355FFT_XCD_RT", "0" if fused == 2 else "1")   # fused=2: the LDS-resident instances the register tiles replaced (2^21: 8-line tiles;
+    # fused=1: the shipped route (2^21: the LDS-resident 1024 x 2048 instance); fused=3 / 4: 2^21 on its register-tile forms, 1024 x 2048 / 2048 x 1024
+    monkeypatch.setenv("MI355FFT_XCD_RT", "0" if fused == 2 else "2" if fused == 3 else "3" if fused == 4 else "1")   # fused=2: the LDS-resident instances the register tiles replaced (2^21: 8-line tiles;
     monkeypatch.setenv("MI355FFT_XCD_HX", "0" if fused == 2 else "2")   #          2^20: 16 x 1024 tiles in LDS)
     monkeypatch.setenv("MI355FFT_MAX_LINE", "4096")       # 2^13 and 2^14 would otherwise run as single-workgroup lines
     monkeypatch.setenv("MI355FFT_LINE32K", "0")           # ... and so would 2^15 (kern_line32k.hpp, test_c2c_line32k)
@@ -142,7 +143,7 @@ def test_c2c_two_pass(fft, dev, oracle, monkeypatch, lg, fused):
     x = oracle.random_complex_batch(n, batch, 0xB000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, _) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "backward"}, x, x.size)
-        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused-rt[" if lg >= 21 and fused == 1 else "xcd-fused-rt32[" if lg == 20 and fused == 1 else "xcd-fused[") if fused else "two-pass["), route
+        assert route.startswith(("xcd-solo[" if lg <= 17 else "xcd-fused-rt[" if (lg == 22 and fused == 1) or fused == 3 else "xcd-fused-rt32[" if (lg == 20 and fused == 1) or fused == 4 else "xcd-fused[") if fused else "two-pass["), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "backward"), f"{route.strip()} 2^{lg} {direction}")
 
 
@@ -255,7 +256,7 @@ def test_c2c_fused_many_transforms(fft, dev, oracle, monkeypatch, lg, batch):
     x = oracle.random_complex_batch(n, batch, 0xC000 + lg).reshape(-1)
     for direction in ("forward", "inverse"):
         got, (route, launches) = run_plan(fft, dev, {"type": "c2c", "shape": [n], "batch": batch, "direction": direction, "normalize": "none"}, x, x.size)
-        assert (route.startswith("xcd-solo[") and launches == 1) if lg <= 17 else (route.startswith("xcd-fused-rt[" if lg >= 21 else "xcd-fused[") and launches == 2), route
+        assert (route.startswith("xcd-solo[") and launches == 1) if lg <= 17 else (route.startswith("xcd-fused-rt[" if lg == 22 else "xcd-fused[") and launches == 2), route
         check(oracle, got, oracle.c2c_ref_batch(x, [n], batch, direction, "none"), f"fused 2^{lg} x{batch} {direction}")
 
 

@@ -143,7 +143,7 @@ template <class L> bool launch_fftconv_fused(int id, const FusedConvArgs& a, uns
 #define MI_XCD_PLUS2(...) +2
 #define MI_XCD_PLUS1(...) +1
 constexpr int XCD_INSTANCE_COUNT = 0 MI355_XCD_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_R2C_KERNEL_LIST(MI_XCD_PLUS1) MI355_XCD_C2R_KERNEL_LIST(MI_XCD_PLUS1)
-                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_RT_KERNEL_LIST(MI_XCD_PLUS2) + 1 + 2 + 1 + 2 + 1 + 1 + 1 + 2 + 2 MI355_XCD_VIEW_KERNEL_LIST(MI_XCD_PLUS2);   // (+ the VIEW instances of the LDS-resident kernels) (+ the VIEW instances of the 32-line 1024 x 1024 kernel) (+ 1024 x 1024 on 16-line register tiles, two 256-thread workgroups per CU: forward, inverse) (+ the register-tile r2c and c2r 1024 x 2048) (+ the fftconv pipeline for 2^20 points) + the register-tile r2c 2048 x 2048 + the two-workgroups-per-CU 1024 x 1024 (forward, inverse) + the register-tile c2r 2048 x 2048 + the 32-line register-tile 1024 x 1024 (forward, inverse)
+                                     MI355_XCD_2D_KERNEL_LIST(MI_XCD_PLUS2) MI355_XCD_RT_KERNEL_LIST(MI_XCD_PLUS2) + 1 + 2 + 1 + 2 + 1 + 1 + 1 + 2 + 2 MI355_XCD_VIEW_KERNEL_LIST(MI_XCD_PLUS2) + 2;   // (+ 2048 x 1024 on register tiles, forward and inverse)   // (+ the VIEW instances of the LDS-resident kernels) (+ the VIEW instances of the 32-line 1024 x 1024 kernel) (+ 1024 x 1024 on 16-line register tiles, two 256-thread workgroups per CU: forward, inverse) (+ the register-tile r2c and c2r 1024 x 2048) (+ the fftconv pipeline for 2^20 points) + the register-tile r2c 2048 x 2048 + the two-workgroups-per-CU 1024 x 1024 (forward, inverse) + the register-tile c2r 2048 x 2048 + the 32-line register-tile 1024 x 1024 (forward, inverse)
 #undef MI_XCD_PLUS2
 #undef MI_XCD_PLUS1
 
@@ -295,6 +295,18 @@ template <int ONLY, class L> bool launch_xcd_sel(int id, const XcdFusedArgs& a, 
   MI355_XCD_VIEW_KERNEL_LIST(X)
 #undef X
 #undef MI_XCD_CASE_VIEW
+  {
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;
+    if constexpr (ONLY < 0 || ONLY == ME) {
+      if (id == ME) { l.launch_concurrent(fft_xcd_rt1k_kernel<false, 32, false, 2048>, grid, 512u, (unsigned)(Rt1kCfg::LDS_BYTES + RtCfg::TW2_ELEMS * 8), a); return true; }
+    }
+  }
+  {
+    constexpr int ME = __COUNTER__ - MI_XCD_COUNTER_BASE;
+    if constexpr (ONLY < 0 || ONLY == ME) {
+      if (id == ME) { l.launch_concurrent(fft_xcd_rt1k_kernel<true, 32, false, 2048>, grid, 512u, (unsigned)(Rt1kCfg::LDS_BYTES + RtCfg::TW2_ELEMS * 8), a); return true; }
+    }
+  }
   static_assert(__COUNTER__ - MI_XCD_COUNTER_BASE == XCD_INSTANCE_COUNT, "instance ids out of step with the lists");
   return false;
 }

@@ -768,18 +768,23 @@ MI_DEV void rt1k_exchange(const cf (&va)[32], const cf (&vb)[32], cf (&w)[32], c
 
 // VIEW (r03; src/kernels/ioview.js:56-380, zero_pad.js:21-80 for a 2^20-point line): pad-in-read / crop / zero ranges are predicates of pass A's
 // loads and pass B's stores (XcdFusedArgs::v_*), so a view of a four-step line needs no embed / zero / extract launch either.
-template <bool INV, int T = 32, bool VIEW = false>
+// N1_ = 2048 (r03, 2^21 as 2048 x 1024): pass A runs the 2048-point columns on the 16-line register tiles above (rt_finish_cols), pass B the
+// 2048 rows of 1024 points on the 32-line tiles — 128- / 256-byte segments on every side (the 1024 x 2048 orientation: LDS-resident 16 x 1024 tiles + 16 x 2048 register tiles).
+template <bool INV, int T = 32, bool VIEW = false, int N1_ = 1024>
 __global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(const XcdFusedArgs f) {   // (2 waves per SIMD: 256 registers per thread, VGPRs + AGPRs, for either tile width)
   using K = Rt1kCfgT<T>;
+  static_assert(N1_ == 1024 || (N1_ == 2048 && T == 32 && !VIEW), "1024 x 1024, or 2048 x 1024 with pass A on 16 x 2048 register tiles");
   MI_SMEM_DECL(smem);
   cf* xb = reinterpret_cast<cf*>(smem);
   cf* tw1 = xb + K::HALF_ELEMS;
-  unsigned* s_words = reinterpret_cast<unsigned*>(tw1 + K::TW1_ELEMS);
+  cf* tw2 = tw1 + K::TW1_ELEMS;                                     // (N1_ = 2048: stage-2 roots of the 2048-point columns)
+  unsigned* s_words = reinterpret_cast<unsigned*>(tw2 + (N1_ == 2048 ? RtCfg::TW2_ELEMS : 0));
   const int t = threadIdx.x;
-  for (int i = t; i < K::TW1_ELEMS; i += K::THREADS) tw1[i] = f.tw_a[i];
+  for (int i = t; i < K::TW1_ELEMS; i += K::THREADS) tw1[i] = f.tw_b[i];
+  if constexpr (N1_ == 2048) { for (int i = t; i < RtCfg::TW2_ELEMS; i += K::THREADS) tw2[i] = f.tw_a[i]; }
   if (!xcd_register(f.ctl, f.split, f.spin_limit, f.sticky_error, s_words)) return;
   const unsigned gslot = s_words[0], rank = s_words[1], gsize = s_words[2], gidx = s_words[4], groups = s_words[5];
-  constexpr unsigned N1 = 1024, N2 = 1024, NT = 1024 / T, TU = (unsigned)T;
+  constexpr unsigned N1 = N1_, N2 = 1024, NT = N1 / T, TU = (unsigned)T;
   const bool two_slots = f.slots != 1u;
   cf* const W0 = f.wslots + (size_t)((two_slots ? 2u : 1u) * gslot) * (size_t)f.N;
   const int cl = t & (T - 1), h = t / T;    // column-side map
@@ -803,7 +808,13 @@ __global__ void __launch_bounds__(Rt1kCfgT<T>::THREADS, 2) fft_xcd_rt1k_kernel(c
     // stage 1 computes and stores; the rest follows at the top of the next iteration.  Off by default: the registers they pin cost more
     // (spills) than the overlap gains.
     // ---- phase A: 32 adjacent columns per tile ----
-    {
+    if constexpr (N1_ == 2048) {
+      for (unsigned tile = rank; tile < N2 / 16; tile += gsize) {
+        cf v[64];
+        rt_load_cols<INV, RT_NT_IN>(v, x, N2, tile * 16u, t);
+        rt_finish_cols(v, W, N2, tile * 16u, t, xb, tw2, [](cf (&)[64]) {});
+      }
+    } else {
       cf va[32], vb[32], w[32];
       const unsigned voff = (unsigned)h * N2 + (unsigned)cl;
       constexpr int PF = MI355_RT1K_PREFETCH;     // how many of va's 32 loads are requested one tile ahead

@@ -161,6 +161,9 @@ const std::vector<XcdKernelMeta>& xcd_kernel_registry() {
   }
     MI355_XCD_VIEW_KERNEL_LIST(X)
 #undef X
+    for (int inv = 0; inv < 2; ++inv) {   // 2^21 as 2048 x 1024: 16-line register tiles down the columns, 32-line register tiles along the rows (fft_xcd_rt1k_kernel<.., 2048>): rt = 7
+      XcdKernelMeta m{id++, 2048, 1024, {64, 32, 1}, {32, 32, 1}, 16, 32, inv != 0, 512, (32 * 32 * 16 + 31 * 32 + 31 * 64) * 8 + 64, 0, 7}; r.push_back(m);
+    }
     return r;
   }();
   return reg;
@@ -724,7 +727,15 @@ struct Builder {
       const int64_t F1 = (int64_t)1 << (lgf / 2), F2 = N / F1;
       const XcdKernelMeta* xm = nullptr;
       for (const auto& m : xcd_kernel_registry())
-        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : m.rt == 5 ? opt.xcd_hx == 3 : m.rt == 6 ? false : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
+        if (!m.real && m.N1 == F1 && m.N2 == F2 && m.inverse == inverse && (!m.rt || ((m.rt == 2 ? opt.xcd_hx == 1 : m.rt == 3 ? opt.xcd_hx == 2 : m.rt == 5 ? opt.xcd_hx == 3 : m.rt == 6 || m.rt == 7 ? false : opt.xcd_rt != 0) && opt.xcd_shared))) xm = &m;
+      // c2c 2^21: with two groups per XCD and one slot each the LDS-resident 1024 x 2048 instance (8-line tiles taken in pairs) runs at 177
+      // GPoints/s, ahead of both register-tile forms — 2048 x 1024 (16-line tiles down the columns, 32-line tiles along the rows;
+      // MI355FFT_XCD_RT=3) 172, 1024 x 2048 (MI355FFT_XCD_RT=2) 162: profiles/r03_regtile_ab.log.  So the register tiles serve 2^22 only.
+      if (N == ((int64_t)1 << 21) && opt.xcd_rt != 2) {
+        xm = nullptr;
+        for (const auto& m : xcd_kernel_registry())
+          if (!m.real && m.inverse == inverse && ((opt.xcd_rt == 3 && opt.xcd_shared) ? m.rt == 7 : (!m.rt && m.N1 == F1 && m.N2 == F2))) xm = &m;
+      }
       if (xm && (N > 4096 || opt.xcd_fused == 2) &&
           (opt.xcd_shared || ((uint64_t)N * 8 <= ((uint64_t)opt.solo_max_kb << 10) && opt.xcd_fused != 2))) {
         const bool a_rt = xm->rt == 1 && xm->N1 == 2048;   // register-tile passes take their stage-2 table instead of a line kernel's
@@ -751,7 +762,7 @@ struct Builder {
         std::vector<float2h> lo((size_t)1 << shift), hi((size_t)std::max<int64_t>(1, N >> shift));
         for (size_t l = 0; l < lo.size(); ++l) lo[l] = root_of_unity((int64_t)l, N);
         for (size_t h = 0; h < hi.size(); ++h) hi[h] = root_of_unity((int64_t)h << shift, N);
-        const PtrRef tb = xm->rt == 1 ? regtile_table() : line_tables(mb), ta = a_rt ? tb : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
+        const PtrRef tb = xm->rt == 1 ? regtile_table() : line_tables(mb), ta = a_rt ? tb : xm->rt == 7 ? regtile_table() : line_tables(ma), tlo = add_table(lo), thi = add_table(hi);
         if (!solo) { Step& z = push(ST_ZERO); z.p[0] = ctl; z.i[0] = 9216; z.grid = 1; }
         Step& st = push(ST_XCD_FUSED);
         st.variant = xm->id;
@@ -764,7 +775,7 @@ struct Builder {
         // shared mode: every workgroup must be co-resident — one per CU, two where 256 threads and <= 80 KB of LDS leave room
         if (!solo && opt.xcd_fused != 2 && ((xm->threads <= 256 && xm->lds_bytes <= 80 * 1024) || xm->rt == 2)) grid *= 2;
         st.grid = (unsigned)grid;
-        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt == 3 ? "xcd-fused-rt32[N=" : xm->rt == 5 ? "xcd-fused-rt16x2[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
+        ir.route += std::string(solo ? "xcd-solo[N=" : xm->rt == 2 ? "xcd-fused-2wg[N=" : xm->rt == 3 ? "xcd-fused-rt32[N=" : xm->rt == 5 ? "xcd-fused-rt16x2[N=" : xm->rt == 7 ? "xcd-fused-rt32[N=" : xm->rt ? "xcd-fused-rt[N=" : "xcd-fused[N=") + std::to_string(xm->N1) + "x" + std::to_string(xm->N2) + "] ";
         return MI355FFT_OK;
       }
     }

@@ -166,7 +166,8 @@ struct PlannerOptions {
   int xcd_res = 0;                     // N = 2^20: XCD-resident kernel (kern_xcd_res.hpp): 1 on, 2 = its data-movement skeleton without arithmetic (measurement only)
   int xcd_res_depth = 4;               // exchange channels in flight per XCD (1, 2, 4): 1 MiB of L2-resident buffer each
   int xcd_split = 0;                   // groups per XCD in the fused kernels (1..8); 0 = chosen per plan from the workspace footprint
-  int xcd_rt = 1;                      // 2048-point sides on register tiles (kern_regtile.hpp) where an instance exists (0: the LDS-resident 8-line tiles / two-pass route)
+  int xcd_rt = 1;                      // 2048-point sides on register tiles (kern_regtile.hpp) where an instance exists (0: the LDS-resident 8-line tiles / two-pass route;
+                                       // c2c 2^21 stays on the LDS-resident instance unless 2: 1024 x 2048 on register tiles, 3: 2048 x 1024 on register tiles)
   int xcd_hx = 2;                      // N = 2^20: 2 = 32-line register tiles (kern_regtile.hpp fft_xcd_rt1k_kernel; r03 default: 199 vs 194 GPoints/s), 1 = two workgroups per CU on 16-line
                                        // register tiles (fft_xcd_hx_kernel: 171), 0 = the LDS-resident fused kernel (kern_xcd.hpp)
   int xcd_2d = 1;                      // 2-D c2c planes with an instance: both axes in one fused launch
