@@ -63,6 +63,7 @@ const std::vector<MixedCtMeta>& mixedct_registry();
   X(64, 8, 8, 1, 16, 64, 8, 8, 1, 16) X(128, 16, 8, 1, 32, 256, 16, 16, 1, 16) X(256, 16, 16, 1, 16, 256, 16, 16, 1, 16) \
   X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) \
   X(1024, 32, 32, 1, 16, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
+// (2^22 = 2048 x 2048 on LDS-resident 8-line tiles, re-measured in r03 with the one-slot grouping: 89-105 vs 159 GPoints/s for the register tiles: profiles/r03_regtile_ab.log)
 // (2^20 with 1024 threads and 16-point register stages — 16 waves per CU instead of 8, 128 VGPRs, 56 B of scratch — measured
 // 165-176 vs 186 GPoints/s: profiles/r02_xcd_2p21_orientation.log; not instantiated)
 // (2^21 as 2048 x 1024 — 64-byte segments on the input side instead of the output side — measured 138 vs 167 GPoints/s for
