@@ -794,6 +794,12 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 //
 // MAPPED (r02): the packed bins are read through a.imap (zeros outside its box) and the real line leaves the
 // LDS line buffer through a.omap (element = one float), as in the r2c kernel above.
+#ifndef MI355_C2R_RAW_COPY
+#define MI355_C2R_RAW_COPY 1
+#endif
+#ifndef MI355_C2R_RAW_COPY_H
+#define MI355_C2R_RAW_COPY_H 8192
+#endif
 #ifndef MI355_C2R_PV_8K
 #define MI355_C2R_PV_8K 1
 #endif
@@ -839,7 +845,28 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         [[maybe_unused]] long long ibase = 0;
         [[maybe_unused]] bool izero = false, iline = false;
         if constexpr (MAPPED) iline = side_line(a.imap, G0 + t / C::TPL, a.num_lines, ibase, izero);
-        if constexpr (!TRIG && !MAPPED && MI355_C2R_PRE_VEC && H >= 2048) {
+        if constexpr (!TRIG && !MAPPED && MI355_C2R_RAW_COPY && H == MI355_C2R_RAW_COPY_H && C::T == 1) {
+          // r03 (N = 2^14, one line per 256-thread workgroup): the packed line is first copied into its LDS slot as it is — a plain strided
+          // loop whose loads are all independent: 16-32 of them in flight per thread where the pair loop below has 2-4 — and the pre-split then
+          // runs IN the slot (a pair (k, H-k) is read and rewritten by one lane; roots from the cache-resident tables).  Same box
+          // (profiles/r03_c2r_raw_copy.log): N = 2^14 386 -> 422 G real samples/s; N = 2^15 (512 threads, one workgroup per CU) 372 -> 350: not used there
+          const cf* x = a.in + G0 * a.in_outer_stride;
+          cf* xl = lds;
+#pragma unroll 16
+          for (int i = t; i < H + 1; i += C::THREADS) xl[i] = x[i];
+          __syncthreads();
+          const cf xh = xl[H];
+          for (int k = t; k <= H / 2; k += C::THREADS) {
+            cf pk = xl[k], m = k == 0 ? xh : xl[H - k];
+            if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
+            const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
+            const cf mc = {m.x, -m.y};
+            const cf e = pk + mc;
+            const cf o = cmul_conj(pk - mc, w);
+            xl[k] = e + mul_pos_i(o);
+            if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
+          }
+        } else if constexpr (!TRIG && !MAPPED && MI355_C2R_PRE_VEC && H >= 2048) {
           // (N >= 4096: below that the pair-per-lane batches further down measured 5-10 % faster, profiles/r02_split_vec_ab.log)
           // two adjacent bins per lane: X[k], X[k+1] and their mirrors X[H-k-1], X[H-k] arrive as two 16-byte loads (k odd; the last
           // item ends on the self-mirrored bin H/2; bins 0 / H are an item of their own), PV items' loads in flight at a time
