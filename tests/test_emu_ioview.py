@@ -173,7 +173,7 @@ def test_c2c_sides_fused_into_the_line_kernels(oracle, monkeypatch, shape, io_vi
             assert staging and "mapped[" not in route, route
 
 
-@pytest.mark.parametrize("lg,label,clear", [(20, "1024x1024", False), (20, "1024x1024", True), (17, "256x512", False), (18, "512x512", True), (19, "512x1024", False)])
+@pytest.mark.parametrize("lg,label,clear", [(20, "1024x1024", False), (20, "1024x1024", True), (17, "256x512", False), (18, "512x512", True), (19, "512x1024", False), (21, "1024x2048", False)])
 def test_c2c_view_of_a_four_step_line(oracle, monkeypatch, lg, label, clear):
     """r03: a rank-1 view of a 2^20-point line — pad-in-read (the input view is shorter and shifted), zeroPad.read / .write ranges, crop +
     embed-in-write (the output view is a shifted window, optionally cleared outside) — as predicates of the fused kernel's loads and stores

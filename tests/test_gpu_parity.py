@@ -436,7 +436,7 @@ def test_r2c_c2r_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
     assert np.count_nonzero(got == 77.0) == (5000 - n) * batch
 
 
-@pytest.mark.parametrize("lg,fuse", [(20, 1), (20, 0), (17, 1), (18, 1), (19, 1)])
+@pytest.mark.parametrize("lg,fuse", [(20, 1), (20, 0), (17, 1), (18, 1), (19, 1), (21, 1)])
 def test_c2c_view_of_a_four_step_line(fft, dev, oracle, monkeypatch, lg, fuse):
     """r03: rank-1 ioView + zeroPad of a 2^20-point line as predicates of the fused kernel's loads and stores (fuse=1: control-block reset +
     one launch, route free of embed / zero / extract) against the staging route (fuse=0) and the numpy restatement of the semantics"""

@@ -91,10 +91,10 @@ const std::vector<MixedCtMeta>& mixedct_registry();
 // registers (128-byte segments where the LDS-resident 8-line tiles above move 64-byte ones); forward and inverse.  Listed AFTER
 // the LDS-resident instances of the same size so that a registry walk finds them last (PlannerOptions::xcd_rt).
 #define MI355_XCD_RT_KERNEL_LIST(X) X(1024) X(2048)
-// VIEW instantiations of the LDS-resident fused kernel (rank-1 ioView / zeroPad ranges as load / store predicates): 2^17, 2^18, 2^19, forward and inverse
+// VIEW instantiations of the LDS-resident fused kernel (rank-1 ioView / zeroPad ranges as load / store predicates): 2^17, 2^18, 2^19, 2^21, forward and inverse
 // (2^20 has its own in kern_regtile.hpp).  Same parameters as MI355_XCD_KERNEL_LIST.
 #define MI355_XCD_VIEW_KERNEL_LIST(X) \
-  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16)
+  X(256, 16, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 16, 512, 32, 16, 1, 16) X(512, 32, 16, 1, 32, 1024, 32, 32, 1, 16) X(1024, 32, 32, 1, 16, 2048, 32, 32, 2, 8)
 struct XcdKernelMeta { int id, N1, N2, ra[3], rb[3], ta, tb; bool inverse; int threads, lds_bytes; int real; int rt; };   // real: 0 c2c, 1 r2c, 2 c2r, 3 two-dimensional c2c, 4 fftconv pipeline; rt: 1 register-tile instance (2048-point sides), 2 the two-workgroups-per-CU 1024 x 1024
 const std::vector<XcdKernelMeta>& xcd_kernel_registry();
 const std::vector<ConvKernelMeta>& conv_kernel_registry();
