@@ -16,6 +16,16 @@
 #pragma once
 #include "kern_xcd.hpp"
 
+// The packed side of the real transforms has rows of N/2 + 1 bins: every 128-byte run starts on an odd 8-byte offset and shares its first and last
+// cache line with the neighbouring tiles' runs.  r03 (profiles/r03_real_packed_side_nt_ab.log): temporal accesses on that side let those partial lines
+// meet in the L2.
+#ifndef MI355_XCD_R2C_NT_OUT
+#define MI355_XCD_R2C_NT_OUT 0   /* temporal: r2c 2^17 265 -> 314, 2^18 257 -> 338, 2^19 297 -> 358, 2^20 318 -> 331 G real points/s */
+#endif
+#ifndef MI355_XCD_C2R_NT_IN
+#define MI355_XCD_C2R_NT_IN 1    /* nontemporal stays: temporal loads measured 0 ... -5 % on the LDS-resident c2r kernels (the register-tile 2^22 kernel, whose tiles are larger, gains 6 % and uses them) */
+#endif
+
 namespace mi355 {
 
 typedef float cf4 __attribute__((ext_vector_type(4)));
@@ -141,12 +151,12 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_r2c_kernel(const XcdFused
             if (ab.scale != 1.0f) r = r * ab.scale;
             const int uni = (b * CB::TPL + q * I::NSP) * N1;     // uniform part of k = k1 + N1*k2, k2 = j + q*(N2/R)
             if (q < I::R / 2) {
-              if (live) st_stream<PairOf<CB, false>::NT>(po + (uni + voff), r);
+              if (live) st_stream<PairOf<CB, false>::NT && MI355_XCD_R2C_NT_OUT>(po + (uni + voff), r);
             } else {
               // k > N/2 (or = N/2 for k1 = 0, k2 = N2/2, which is its own mirror and stays unconjugated)
               const bool nyq = k1 == 0 && q == I::R / 2 && j == 0;
               cf m; m.x = r.x; m.y = nyq ? r.y : -r.y;
-              if (live && (!edge || nyq)) st_stream<PairOf<CB, false>::NT>(po + ((int)f.N - uni - voff), m);
+              if (live && (!edge || nyq)) st_stream<PairOf<CB, false>::NT && MI355_XCD_R2C_NT_OUT>(po + ((int)f.N - uni - voff), m);
             }
           }
         }
@@ -230,8 +240,8 @@ __global__ void __launch_bounds__(CA::THREADS) fft_xcd_c2r_kernel(const XcdFused
 #pragma unroll
         for (int q = 0; q < I::R; ++q) {
           const int step = q * (N1 / I::R) * N2;             // uniform
-          if (q < I::R / 2) { const cf x = ld_stream<PairOf<CA, false>::NT>(X + (up + step)); v[q] = cf{x.x, -x.y}; }
-          else v[q] = ld_stream<PairOf<CA, false>::NT>(X + (lo - step));
+          if (q < I::R / 2) { const cf x = ld_stream<PairOf<CA, false>::NT && MI355_XCD_C2R_NT_IN>(X + (up + step)); v[q] = cf{x.x, -x.y}; }
+          else v[q] = ld_stream<PairOf<CA, false>::NT && MI355_XCD_C2R_NT_IN>(X + (lo - step));
         }
       }
       stage_compute_write<CA, 0>(v, aa, tile, t, lds, tw_a, nullptr);
