@@ -372,7 +372,7 @@ def test_r2c_and_c2r(oracle, n):
     check(back, x, f"c2r(r2c) round trip N={n}", 1e-5)
 
 
-@pytest.mark.parametrize("n", [128, 256, 2048, 8192, 16384])     # 16384: the c2r twin copies the packed line raw into LDS and pre-splits in place (r03)
+@pytest.mark.parametrize("n", [128, 256, 2048, 4096, 8192, 16384, 32768])     # 4096 ... 16384 (4096: two lines per tile, the odd batch leaves a ragged one), 32768 opt-in: the c2r twin copies the packed line raw into LDS and pre-splits in place (r03)
 def test_r2c_split_fused_into_the_line_kernel(oracle, monkeypatch, n):
     """even N with a power-of-two half length >= 64: ONE launch (line FFT of the packed pairs + split from LDS); same numbers as
     the two-launch route"""

@@ -503,7 +503,7 @@ def test_c2c_ioview_and_zeropad(fft, dev, oracle, monkeypatch, fuse):
 
 # ---- r2c / c2r ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("lines_r2c", [1, 0])
-@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 128, 1024, 4096, 8192, 1 << 15, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21, 17])
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 64, 128, 1024, 4096, 8192, 1 << 14, 1 << 15, 1 << 16, 1 << 20, 6, 10, 30, 9, 15, 21, 17])
 def test_r2c_c2r(fft, dev, oracle, monkeypatch, n, lines_r2c):
     """every r2c / c2r route by length; lines_r2c: the split fused into the line kernel (one launch, half lengths 64..16384 for
     r2c, 2..16384 for c2r) or the two-launch route"""

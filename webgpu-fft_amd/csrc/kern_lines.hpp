@@ -798,7 +798,10 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 #define MI355_C2R_RAW_COPY 1
 #endif
 #ifndef MI355_C2R_RAW_COPY_H
-#define MI355_C2R_RAW_COPY_H 8192
+#define MI355_C2R_RAW_COPY_H 2048
+#endif
+#ifndef MI355_C2R_RAW_COPY_HMAX
+#define MI355_C2R_RAW_COPY_HMAX 8192
 #endif
 #ifndef MI355_C2R_PV_8K
 #define MI355_C2R_PV_8K 1
@@ -812,8 +815,14 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 #ifndef MI355_C2R_PRE_BATCH
 #define MI355_C2R_PRE_BATCH 4
 #endif
+// one-line 256-thread workgroups (N = 2^14, a 64 KB line each): capped at 256 registers a wave, two to a CU.  Uncapped, the raw-copy head
+// takes 256 + 46..56 AGPRs and the code the compiler makes of that is either as fast (489) or much slower (289-300), depending on details
+// of the source that should not matter (profiles/r03_c2r_raw_roots.log)
+#ifndef MI355_LINES_C2R_MINW
+#define MI355_LINES_C2R_MINW 2
+#endif
 template <class C, bool TRIG = false, bool MAPPED = false>
-__global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArgs a) {
+__global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 ? MI355_LINES_C2R_MINW : 1) fft_lines_c2r_kernel(const LineArgs a) {
   static_assert(!C::IN_COL && !C::OUT_COL && C::SWAP_IN && C::SWAP_OUT && C::TWID == TWID_NONE, "inverse ROW configuration");
   static_assert(!(TRIG || MAPPED) || C::NSTAGES >= 2, "the fused DCT-III and the mapped sides need the LDS line buffer");
   static_assert(!(TRIG && MAPPED), "the fused DCT-III takes dense lines");
@@ -829,6 +838,11 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
   [[maybe_unused]] constexpr int NREAL = 2 * H;
   [[maybe_unused]] const bool sine = TRIG && a.real_mode == 8;
   using I0 = StageInfo<C, 0>;
+  // raw copy of the packed lines (2048 <= H <= 8192; see the head of the tile loop): TPL threads per line, lane ru of line rl takes bins ru + TPL i
+  constexpr bool RAW = !TRIG && !MAPPED && MI355_C2R_RAW_COPY && C::NSTAGES >= 2 && H >= MI355_C2R_RAW_COPY_H && H <= MI355_C2R_RAW_COPY_HMAX;
+  constexpr int RAWN = RAW ? H / C::TPL : 1, RAW_WL = RAW ? 1024 / C::TPL : 1, RAW_NK = (H / 2) / C::TPL, RAW_NWH = H / 2048 + 1;
+  static_assert(!RAW || (1024 % C::TPL == 0 && (H / 2) % C::TPL == 0 && H >= 2048), "k = ru + TPL i walks the LO table in whole strides");
+  [[maybe_unused]] const int rl = C::T == 1 ? 0 : t / C::TPL, ru = C::T == 1 ? t : t % C::TPL;
   for (long long tile = blockIdx.x; tile < a.num_tiles; tile += gridDim.x) {
     cf v[C::E];
     {
@@ -845,27 +859,44 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_c2r_kernel(const LineArg
         [[maybe_unused]] long long ibase = 0;
         [[maybe_unused]] bool izero = false, iline = false;
         if constexpr (MAPPED) iline = side_line(a.imap, G0 + t / C::TPL, a.num_lines, ibase, izero);
-        if constexpr (!TRIG && !MAPPED && MI355_C2R_RAW_COPY && H == MI355_C2R_RAW_COPY_H && C::T == 1) {
-          // r03 (N = 2^14, one line per 256-thread workgroup): the packed line is first copied into its LDS slot as it is — a plain strided
+        if constexpr (RAW) {
+          // r03 (first for N = 2^14, one line per 256-thread workgroup): the packed line is first copied into its LDS slot as it is — a plain strided
           // loop whose loads are all independent: 16-32 of them in flight per thread where the pair loop below has 2-4 — and the pre-split then
           // runs IN the slot (a pair (k, H-k) is read and rewritten by one lane; roots from the cache-resident tables).  Same box
-          // (profiles/r03_c2r_raw_copy.log): N = 2^14 386 -> 422 G real samples/s; N = 2^15 (512 threads, one workgroup per CU) 372 -> 350: not used there
-          const cf* x = a.in + G0 * a.in_outer_stride;
-          cf* xl = lds;
-#pragma unroll 16
-          for (int i = t; i < H + 1; i += C::THREADS) xl[i] = x[i];
+          // (profiles/r03_c2r_raw_copy.log): N = 2^14 386 -> 422 G real samples/s; N = 2^15 (512 threads, one workgroup per CU) 372 -> 350 in that first form.
+          // The roots of the in-slot loop leave with the copy's loads: k = t + THREADS i, so with the 1024-entry LO table (fs_shift = 10,
+          // plan.cpp emit_lines_r2c) a lane needs 1024 / THREADS LO roots and the HI root is the same for the whole workgroup; the loop itself
+          // is LDS and arithmetic only (with the table loads inside it every trip waited out a cache latency): N = 2^14 423 -> 488,
+          // N = 2^13 515 -> 564, N = 2^12 (two lines per workgroup) 547 -> 574.
+          // N = 2^15 (MI355_C2R_RAW_COPY_HMAX=16384; one 512-thread workgroup per CU, 20 registers spilled) 371 -> 362 / 378 -> 393 on two
+          // boxes: not used; with the NEXT line's loads issued ahead into registers (64 more live through the stages) it spills 87 and
+          // runs at 263 (profiles/r03_c2r_raw_roots.log).
+          cf* xl = lds + rl * C::PITCH;
+          const cf* x = a.in + (G0 + (rl < live ? rl : live - 1)) * a.in_outer_stride;    // (a ragged last tile: the spare lines repeat the last one)
+          cf raw[RAWN], wl[RAW_WL], whs[RAW_NWH];       // (per tile: kept across the stages they would cost the stages their registers)
+#pragma unroll
+          for (int i = 0; i < RAWN; ++i) raw[i] = x[ru + i * C::TPL];
+          const cf rawh = x[H];
+#pragma unroll
+          for (int c = 0; c < RAW_WL; ++c) wl[c] = a.tw_lo[ru + c * C::TPL];
+#pragma unroll
+          for (int c = 0; c < RAW_NWH; ++c) whs[c] = a.tw_hi[c];
+#pragma unroll
+          for (int i = 0; i < RAWN; ++i) xl[ru + i * C::TPL] = raw[i];
+          if (ru == 0) xl[H] = rawh;
           __syncthreads();
-          const cf xh = xl[H];
-          for (int k = t; k <= H / 2; k += C::THREADS) {
-            cf pk = xl[k], m = k == 0 ? xh : xl[H - k];
+          const auto pre = [&](int k, cf w) {
+            cf pk = xl[k], m = xl[H - k];
             if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
-            const cf w = cmul(a.tw_hi[(unsigned)k >> a.fs_shift], a.tw_lo[(unsigned)k & a.fs_lo_mask]);
             const cf mc = {m.x, -m.y};
             const cf e = pk + mc;
             const cf o = cmul_conj(pk - mc, w);
             xl[k] = e + mul_pos_i(o);
             if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
-          }
+          };
+#pragma unroll
+          for (int i = 0; i < RAW_NK; ++i) pre(ru + i * C::TPL, cmul(whs[i / RAW_WL], wl[i % RAW_WL]));
+          if (ru == 0) pre(H / 2, cmul(whs[RAW_NWH - 1], wl[0]));      // the self-mirrored bin: (H/2) & 1023 = 0
         } else if constexpr (!TRIG && !MAPPED && MI355_C2R_PRE_VEC && H >= 2048) {
           // (N >= 4096: below that the pair-per-lane batches further down measured 5-10 % faster, profiles/r02_split_vec_ab.log)
           // two adjacent bins per lane: X[k], X[k+1] and their mirrors X[H-k-1], X[H-k] arrive as two 16-byte loads (k odd; the last
