@@ -511,11 +511,20 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mapped_kernel(const Line
 #ifndef MI355_R2C_POST_VEC
 #define MI355_R2C_POST_VEC 1
 #endif
+#ifndef MI355_R2C_POST_ROOTS
+#define MI355_R2C_POST_ROOTS 1
+#endif
+#ifndef MI355_R2C_POST_ROOTS_H
+#define MI355_R2C_POST_ROOTS_H 2048
+#endif
+#ifndef MI355_R2C_POST_ROOTS_HMAX
+#define MI355_R2C_POST_ROOTS_HMAX 4096
+#endif
 #ifndef MI355_R2C_POST_BATCH
 #define MI355_R2C_POST_BATCH 1
 #endif
 template <class C, bool TRIG = false, bool MAPPED = false>
-__global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArgs a) {
+__global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 && !MAPPED ? 2 : 1) fft_lines_r2c_kernel(const LineArgs a) {   // (N = 2^14: two workgroups per CU, see fft_lines_c2r_kernel)
   static_assert(!C::IN_COL && !C::OUT_COL && !C::SWAP_IN && !C::SWAP_OUT && C::TWID == TWID_NONE && C::NSTAGES >= 2, "forward ROW configuration with an LDS line buffer");
   static_assert(!(TRIG && MAPPED), "the fused DCT-II takes dense lines");
   MI_SMEM_DECL(smem);
@@ -598,6 +607,52 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_r2c_kernel(const LineArg
     [[maybe_unused]] long long obase = 0;
     [[maybe_unused]] bool ozero = false, oline = false;
     if constexpr (MAPPED) oline = side_line(a.omap, G0 + t / C::TPL, a.num_lines, obase, ozero);
+    if constexpr (!TRIG && !MAPPED && MI355_R2C_POST_VEC && MI355_R2C_POST_ROOTS && H >= MI355_R2C_POST_ROOTS_H && H <= MI355_R2C_POST_ROOTS_HMAX && 1024 % (2 * C::TPL) == 0 && (H / 4) % C::TPL == 0) {
+      // r03: the form below with the loop's table loads taken out of it (as in the c2r twin's raw-copy head): lane ru of a line takes the
+      // items j = ru + TPL i, i.e. bins k = 2 ru + 1 + 2 TPL i and k + 1; with the 1024-entry LO table that is 1024 / (2 TPL) LO roots per lane and
+      // bin, and the HI root is the same for the whole line (k + 1 crosses into the next HI block on the line's last lane only).
+      // Same box (profiles/r03_r2c_post_roots.log): N = 2^12 585 -> 607, 2^13 557 -> 603 G real samples/s; the 8 / 16 trips of N = 2^14 / 2^15
+      // unrolled this way lose (526 -> 430, 513 -> 353) and keep the loop below
+      typedef float f4w __attribute__((ext_vector_type(4), aligned(8)));
+      constexpr int QP = H / 4, S = 2 * C::TPL, WL = 1024 / S, NI = QP / C::TPL, NWH = (NI + WL - 1) / WL + 1;
+      const int rl = C::T == 1 ? 0 : t / C::TPL, ru = C::T == 1 ? t : t % C::TPL;
+      if (rl < live) {
+        cf wl0[WL], wl1[WL], whs[NWH];
+#pragma unroll
+        for (int c = 0; c < WL; ++c) { wl0[c] = a.tw_lo[2 * ru + 1 + S * c]; wl1[c] = a.tw_lo[(2 * ru + 2 + S * c) & 1023]; }
+#pragma unroll
+        for (int c = 0; c < NWH; ++c) whs[c] = a.tw_hi[c];
+        const bool last_lane = ru == C::TPL - 1;
+        cf* x = a.out + (G0 + rl) * a.out_outer_stride;
+        const auto split = [&](cf zk, cf zm0, cf w, cf& xk, cf& xm) {
+          const cf zmc = {zm0.x, -zm0.y};
+          const cf e = (zk + zmc) * 0.5f;
+          const cf od = mul_neg_i((zk - zmc) * 0.5f);
+          const cf wo = cmul(w, od);
+          xk = (e + wo) * a.scale;
+          xm = (e - wo) * a.scale;
+          xm.y = -xm.y;
+        };
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int k = 2 * (ru + C::TPL * i) + 1;
+          const cf h1 = (i % WL == WL - 1 && last_lane) ? whs[i / WL + 1] : whs[i / WL];
+          cf xk0, xm0, xk1, xm1;
+          split(lds[lds_index<C>(rl, k)], lds[lds_index<C>(rl, H - k)], cmul(whs[i / WL], wl0[i % WL]), xk0, xm0);
+          split(lds[lds_index<C>(rl, k + 1)], lds[lds_index<C>(rl, H - k - 1)], cmul(h1, wl1[i % WL]), xk1, xm1);
+          *reinterpret_cast<f4w*>(x + k) = f4w{xk0.x, xk0.y, xk1.x, xk1.y};
+          if (k + 1 == H / 2) x[H - k] = xm0;                                   // X[H/2] is its own mirror: already stored
+          else *reinterpret_cast<f4w*>(x + (H - k - 1)) = f4w{xm1.x, xm1.y, xm0.x, xm0.y};
+        }
+        if (ru == 0) {
+          const cf z0 = lds[lds_index<C>(rl, 0)];
+          x[0] = cf{(z0.x + z0.y) * a.scale, 0.0f};
+          x[H] = cf{(z0.x - z0.y) * a.scale, 0.0f};
+        }
+      }
+      __syncthreads();   // LDS is re-used by the next tile
+      continue;
+    }
     if constexpr (!TRIG && !MAPPED && MI355_R2C_POST_VEC) {
       // two adjacent bins per lane: X[k], X[k+1] leave as ONE 16-byte store and so do their mirrors X[H-k-1], X[H-k] (k odd, so that
       // the last item ends on the self-mirrored bin H/2); bin 0 / H is an item of its own.  Half the loop trips and store
