@@ -940,8 +940,10 @@ __global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 ? M
           for (int i = 0; i < RAWN; ++i) xl[ru + i * C::TPL] = raw[i];
           if (ru == 0) xl[H] = rawh;
           __syncthreads();
-          const auto pre = [&](int k, cf w) {
-            cf pk = xl[k], m = xl[H - k];
+          // all of a lane's pairs are read before the first is rewritten: interleaved, every read had to wait for the write before it
+          // (the compiler cannot tell that k' and H - k' of a later trip differ from this trip's k and H - k): c2r 2^14 473 -> 499, 2^12 / 2^13 +1 %
+          // (profiles/r03_c2r_2p15_bounds.log; the same log prices the whole in-slot pass at 13-15 % of the launch)
+          const auto pre = [&](cf pk, cf m, int k, cf w) {
             if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
             const cf mc = {m.x, -m.y};
             const cf e = pk + mc;
@@ -949,9 +951,13 @@ __global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 ? M
             xl[k] = e + mul_pos_i(o);
             if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
           };
+          cf pks[RAW_NK], ms[RAW_NK];
 #pragma unroll
-          for (int i = 0; i < RAW_NK; ++i) pre(ru + i * C::TPL, cmul(whs[i / RAW_WL], wl[i % RAW_WL]));
-          if (ru == 0) pre(H / 2, cmul(whs[RAW_NWH - 1], wl[0]));      // the self-mirrored bin: (H/2) & 1023 = 0
+          for (int i = 0; i < RAW_NK; ++i) { pks[i] = xl[ru + i * C::TPL]; ms[i] = xl[H - (ru + i * C::TPL)]; }
+          const cf pmid = xl[H / 2];
+#pragma unroll
+          for (int i = 0; i < RAW_NK; ++i) pre(pks[i], ms[i], ru + i * C::TPL, cmul(whs[i / RAW_WL], wl[i % RAW_WL]));
+          if (ru == 0) pre(pmid, pmid, H / 2, cmul(whs[RAW_NWH - 1], wl[0]));      // the self-mirrored bin: (H/2) & 1023 = 0
         } else if constexpr (!TRIG && !MAPPED && MI355_C2R_PRE_VEC && H >= 2048) {
           // (N >= 4096: below that the pair-per-lane batches further down measured 5-10 % faster, profiles/r02_split_vec_ab.log)
           // two adjacent bins per lane: X[k], X[k+1] and their mirrors X[H-k-1], X[H-k] arrive as two 16-byte loads (k odd; the last
