@@ -858,6 +858,9 @@ __global__ void __launch_bounds__(C::THREADS) fft_lines_mul_kernel(const LineArg
 #ifndef MI355_C2R_RAW_COPY_HMAX
 #define MI355_C2R_RAW_COPY_HMAX 8192
 #endif
+#ifndef MI355_C2R_RAW_DIRECT_HMAX
+#define MI355_C2R_RAW_DIRECT_HMAX 4096
+#endif
 #ifndef MI355_C2R_PV_8K
 #define MI355_C2R_PV_8K 1
 #endif
@@ -928,21 +931,7 @@ __global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 ? M
           // runs at 263 (profiles/r03_c2r_raw_roots.log).
           cf* xl = lds + rl * C::PITCH;
           const cf* x = a.in + (G0 + (rl < live ? rl : live - 1)) * a.in_outer_stride;    // (a ragged last tile: the spare lines repeat the last one)
-          cf raw[RAWN], wl[RAW_WL], whs[RAW_NWH];       // (per tile: kept across the stages they would cost the stages their registers)
-#pragma unroll
-          for (int i = 0; i < RAWN; ++i) raw[i] = x[ru + i * C::TPL];
-          const cf rawh = x[H];
-#pragma unroll
-          for (int c = 0; c < RAW_WL; ++c) wl[c] = a.tw_lo[ru + c * C::TPL];
-#pragma unroll
-          for (int c = 0; c < RAW_NWH; ++c) whs[c] = a.tw_hi[c];
-#pragma unroll
-          for (int i = 0; i < RAWN; ++i) xl[ru + i * C::TPL] = raw[i];
-          if (ru == 0) xl[H] = rawh;
-          __syncthreads();
-          // all of a lane's pairs are read before the first is rewritten: interleaved, every read had to wait for the write before it
-          // (the compiler cannot tell that k' and H - k' of a later trip differ from this trip's k and H - k): c2r 2^14 473 -> 499, 2^12 / 2^13 +1 %
-          // (profiles/r03_c2r_2p15_bounds.log; the same log prices the whole in-slot pass at 13-15 % of the launch)
+          cf wl[RAW_WL], whs[RAW_NWH];       // (per tile: kept across the stages they would cost the stages their registers)
           const auto pre = [&](cf pk, cf m, int k, cf w) {
             if (k == 0) { pk.y = 0.0f; m.y = 0.0f; }
             const cf mc = {m.x, -m.y};
@@ -951,10 +940,38 @@ __global__ void __launch_bounds__(C::THREADS, C::THREADS == 256 && C::T == 1 ? M
             xl[k] = e + mul_pos_i(o);
             if (k != 0 && H - k != k) { const cf ec = {e.x, -e.y}, oc = {o.x, -o.y}; xl[H - k] = ec + mul_pos_i(oc); }
           };
-          cf pks[RAW_NK], ms[RAW_NK];
+          cf pks[RAW_NK], ms[RAW_NK], pmid;
+          if constexpr (H <= MI355_C2R_RAW_DIRECT_HMAX) {
+            // N <= 8192: a lane loads BOTH bins of its pairs (k ascending, H - k descending: each a contiguous run across the lanes), all of
+            // them and the roots up front, pre-splits in registers and writes Z[k], Z[H-k] into the slot: no pass over the slot, no barrier.
+            // Same box (profiles/r03_c2r_direct.log): 2^12 576 -> 592, 2^13 555 -> 588; 2^14 498 -> 490, which keeps the in-slot pass
 #pragma unroll
-          for (int i = 0; i < RAW_NK; ++i) { pks[i] = xl[ru + i * C::TPL]; ms[i] = xl[H - (ru + i * C::TPL)]; }
-          const cf pmid = xl[H / 2];
+            for (int i = 0; i < RAW_NK; ++i) { pks[i] = x[ru + i * C::TPL]; ms[i] = x[H - (ru + i * C::TPL)]; }
+            pmid = x[H / 2];
+#pragma unroll
+            for (int c = 0; c < RAW_WL; ++c) wl[c] = a.tw_lo[ru + c * C::TPL];
+#pragma unroll
+            for (int c = 0; c < RAW_NWH; ++c) whs[c] = a.tw_hi[c];
+          } else {
+            cf raw[RAWN];
+#pragma unroll
+            for (int i = 0; i < RAWN; ++i) raw[i] = x[ru + i * C::TPL];
+            const cf rawh = x[H];
+#pragma unroll
+            for (int c = 0; c < RAW_WL; ++c) wl[c] = a.tw_lo[ru + c * C::TPL];
+#pragma unroll
+            for (int c = 0; c < RAW_NWH; ++c) whs[c] = a.tw_hi[c];
+#pragma unroll
+            for (int i = 0; i < RAWN; ++i) xl[ru + i * C::TPL] = raw[i];
+            if (ru == 0) xl[H] = rawh;
+            __syncthreads();
+            // all of a lane's pairs are read before the first is rewritten: interleaved, every read had to wait for the write before it
+            // (the compiler cannot tell that k' and H - k' of a later trip differ from this trip's k and H - k): c2r 2^14 473 -> 499
+            // (profiles/r03_c2r_2p15_bounds.log; the same log prices the whole in-slot pass at 13-15 % of the launch)
+#pragma unroll
+            for (int i = 0; i < RAW_NK; ++i) { pks[i] = xl[ru + i * C::TPL]; ms[i] = xl[H - (ru + i * C::TPL)]; }
+            pmid = xl[H / 2];
+          }
 #pragma unroll
           for (int i = 0; i < RAW_NK; ++i) pre(pks[i], ms[i], ru + i * C::TPL, cmul(whs[i / RAW_WL], wl[i % RAW_WL]));
           if (ru == 0) pre(pmid, pmid, H / 2, cmul(whs[RAW_NWH - 1], wl[0]));      // the self-mirrored bin: (H/2) & 1023 = 0
